@@ -1,0 +1,168 @@
+"""Pins the CPU oracle: against outputs captured from the reference's own plugin
+functions (tests/golden/ref_plugin_fixture.npz, made by make_reference_fixtures.py)
+and against transformers' LlamaModel built from the reference's config values."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from chatterbox_vllm_amd.config import T3ModelConfig
+from chatterbox_vllm_amd import weights as W
+from oracle.t3_oracle import (T3Oracle, SamplingSpec, _Stream, build_prompt_ids, make_rope_table,
+                              llama3_inv_freq, postprocess_ids, OFFSET, EOS)
+
+
+def _bf16_from_bits(a):
+    return torch.from_numpy(a.view(np.int16).copy()).view(torch.bfloat16).float()
+
+
+@pytest.fixture(scope="module")
+def fx(golden_dir):
+    return np.load(os.path.join(golden_dir, "ref_plugin_fixture.npz"))
+
+
+@pytest.mark.parametrize("tag", ["en", "mtl"])
+def test_prompt_layout_and_embeddings_match_reference(fx, tag):
+    cfg = T3ModelConfig.english(n_layers=0) if tag == "en" else T3ModelConfig.multilingual(n_layers=0)
+    o = T3Oracle(W.synthetic_state_dict(cfg), n_layers=0, bf16=True)
+    text_ids = fx[f"{tag}_text_ids"].tolist()
+    assert build_prompt_ids(text_ids) == fx[f"{tag}_prompt_ids"].tolist()
+    cond = W.synthetic_cond_emb(voice=3)
+    ce, ue = o.prefill_embeds(text_ids, cond)
+    ref = torch.from_numpy(fx[f"{tag}_embeds_full"])          # fp32 [P, 2048] = cond | uncond
+    # the reference returns the 34 cond rows still in fp32; the engine's input buffer is bf16
+    ref16 = ref.to(torch.bfloat16).float()
+    assert torch.equal(ce, ref16[:, :1024])
+    assert torch.equal(ue, ref16[:, 1024:])
+    # facts about the layout (t3.py:548-569)
+    T = len(text_ids)
+    assert torch.equal(ref[:34, :1024], ref[:34, 1024:]) and torch.equal(ref[:34, :1024], cond)
+    assert torch.count_nonzero(ref[34:34 + T, 1024:]) == 0
+    assert torch.equal(ref[-1, :1024], ref[-1, 1024:])
+    # chunked prefill and prefill-then-decode reproduce the same rows in the reference
+    assert fx[f"{tag}_cut_equals_full"].all() and bool(fx[f"{tag}_mixed_head_equals_full"])
+    assert fx[f"{tag}_tri_rowsum"].tolist() == [float(i + 1) for i in range(T)]
+
+
+@pytest.mark.parametrize("tag", ["en", "mtl"])
+def test_decode_embeddings_match_reference(fx, tag):
+    cfg = T3ModelConfig.english(n_layers=0) if tag == "en" else T3ModelConfig.multilingual(n_layers=0)
+    o = T3Oracle(W.synthetic_state_dict(cfg), n_layers=0)
+    ids = fx[f"{tag}_decode_ids"].tolist()
+    for name in ("embeds_decode_only", "embeds_mixed_tail"):
+        ref = _bf16_from_bits(fx[f"{tag}_{name}"])
+        for r, t in enumerate(ids):
+            e = o.decode_embed(t)[0]
+            assert torch.equal(ref[r, :1024], e) and torch.equal(ref[r, 1024:], e)
+
+
+@pytest.mark.parametrize("tag", ["en", "mtl"])
+def test_cfg_logits_match_reference(fx, tag):
+    cfg = T3ModelConfig.english(n_layers=0) if tag == "en" else T3ModelConfig.multilingual(n_layers=0)
+    o = T3Oracle(W.synthetic_state_dict(cfg), n_layers=0, cfg_scale=float(fx[f"{tag}_cfg_scale"]))
+    hid = _bf16_from_bits(fx[f"{tag}_hidden"])
+    ref = _bf16_from_bits(fx[f"{tag}_logits"])
+    got = o.cfg_logits(o.head_logits(hid[:, :1024]), o.head_logits(hid[:, 1024:]))
+    assert got.shape == (3, 9194)
+    assert torch.isneginf(got[:, :OFFSET]).all() and torch.isneginf(ref[:, :OFFSET]).all()
+    assert torch.equal(got[:, OFFSET:], ref[:, OFFSET:])
+
+
+def test_rope_tables_agree_and_match_known_frequencies():
+    inv = llama3_inv_freq()
+    known = {0: 1.0, 1: 0.66360, 2: 0.44037, 3: 0.29223, 28: 1.2892e-6, 29: 8.5550e-7, 30: 5.6771e-7, 31: 3.7673e-7}
+    for i, v in known.items():
+        assert abs(inv[i].item() - v) <= 1e-4 * v
+    cfg = T3ModelConfig.english()
+    assert torch.equal(W.rope_table(cfg, 4096), make_rope_table(4096))
+
+
+def _hf_llama(n_layers, sd):
+    from transformers import LlamaConfig, LlamaModel
+    hf_cfg = LlamaConfig(  # values of t3-model/config.json:5-32 with hidden_size reset as t3.py:310 does
+        attention_bias=False, attention_dropout=0.0, head_dim=64, hidden_act="silu", hidden_size=1024,
+        initializer_range=0.02, intermediate_size=4096, max_position_embeddings=131072, mlp_bias=False,
+        num_attention_heads=16, num_hidden_layers=n_layers, num_key_value_heads=16, pretraining_tp=1,
+        rms_norm_eps=1e-5, rope_theta=500000.0, tie_word_embeddings=False, use_cache=True, vocab_size=8,
+        rope_scaling={"factor": 8.0, "high_freq_factor": 4.0, "low_freq_factor": 1.0,
+                      "original_max_position_embeddings": 8192, "rope_type": "llama3"})
+    hf_cfg._attn_implementation = "eager"
+    m = LlamaModel(hf_cfg).eval()
+    hsd = {k[5:]: v.float() for k, v in sd.items() if k.startswith("tfmr.")}
+    hsd["embed_tokens.weight"] = torch.zeros(8, 1024)
+    m.load_state_dict(hsd, strict=True)
+    return m
+
+
+def test_llama_block_matches_transformers_fp32():
+    L = 3
+    cfg = T3ModelConfig.english(n_layers=L)
+    sd = W.synthetic_state_dict(cfg)
+    m = _hf_llama(L, sd)
+    o = T3Oracle(sd, n_layers=L, bf16=False)
+    x = torch.randn(19, 1024, generator=torch.Generator().manual_seed(5)) * 0.05
+    with torch.no_grad():
+        y = m(inputs_embeds=x[None], position_ids=torch.arange(19)[None]).last_hidden_state[0]
+    z = o.forward(x, torch.arange(19), _Stream())
+    assert (y - z).abs().max().item() < 2e-5
+    # incremental decode through the oracle's explicit KV equals the one-shot forward
+    st = _Stream()
+    z1 = o.forward(x[:12], torch.arange(12), st)
+    rows = [z1] + [o.forward(x[i:i + 1], torch.tensor([i]), st) for i in range(12, 19)]
+    assert (torch.cat(rows) - z).abs().max().item() < 2e-5
+
+
+def test_bf16_mode_tracks_transformers_bf16():
+    L = 2
+    cfg = T3ModelConfig.english(n_layers=L)
+    sd = W.synthetic_state_dict(cfg)
+    m = _hf_llama(L, sd).to(torch.bfloat16)
+    o = T3Oracle(sd, n_layers=L, bf16=True)
+    x = (torch.randn(9, 1024, generator=torch.Generator().manual_seed(6)) * 0.05).to(torch.bfloat16)
+    with torch.no_grad():
+        y = m(inputs_embeds=x[None], position_ids=torch.arange(9)[None]).last_hidden_state[0].float()
+    z = o.forward(x.float(), torch.arange(9), _Stream())
+    # both round every op output to bf16 but place a few roundings differently (RoPE, softmax)
+    assert (y - z).abs().max().item() <= 4 * 2 ** -7 * max(1.0, y.abs().max().item()) / 4
+
+
+def test_sampler_rules():
+    l = torch.full((9194,), float("-inf"))
+    l[OFFSET + 5], l[OFFSET + 9], l[OFFSET + 7] = 2.0, 2.0, -1.0
+    assert T3Oracle.greedy(l) == OFFSET + 5                       # lowest index wins a tie
+    p = T3Oracle.apply_repetition_penalty(l, [OFFSET + 5, OFFSET + 7, 3], 2.0)
+    assert p[OFFSET + 5] == 1.0 and p[OFFSET + 7] == -2.0 and torch.isneginf(p[3])
+    assert T3Oracle.greedy(p) == OFFSET + 9
+    d = T3Oracle.sampling_distribution(p, SamplingSpec(temperature=0.5, top_p=0.8, min_p=0.05))
+    assert abs(d.sum().item() - 1) < 1e-6 and d[OFFSET + 7] == 0 and d[OFFSET + 9] > d[OFFSET + 5]
+
+
+def test_generate_stop_and_length_rules():
+    cfg = T3ModelConfig.english(n_layers=1)
+    o = T3Oracle(W.synthetic_state_dict(cfg), n_layers=1)
+    cond = W.synthetic_cond_emb(0)
+    text = [255, 10, 20, 2, 30, 0]
+    r = o.generate_one(text, cond, SamplingSpec(max_tokens=5))
+    assert len(r["token_ids"]) == 5 and r["finish_reason"] == "length"
+    assert all(OFFSET <= t < OFFSET + 8194 for t in r["token_ids"])
+    P = len(build_prompt_ids(text))
+    r2 = o.generate_one(text, cond, SamplingSpec(max_tokens=50), max_model_len=P + 3)
+    assert r2["token_ids"] == r["token_ids"][:3]
+    forced = [r["token_ids"][0], EOS + OFFSET]
+    r3 = o.generate_one(text, cond, SamplingSpec(max_tokens=50), forced=forced)
+    assert r3["finish_reason"] == "stop" and r3["token_ids"][-1] == EOS + OFFSET
+    with pytest.raises(ValueError):
+        o.generate_one(text, cond, SamplingSpec(), max_model_len=P - 1)
+    # single-stream (CFG off) equals paired with scale 0
+    o0 = T3Oracle(W.synthetic_state_dict(cfg), n_layers=1, cfg_scale=0.0)
+    a = o0.generate_one(text, cond, SamplingSpec(max_tokens=4), paired=True)["token_ids"]
+    b = o0.generate_one(text, cond, SamplingSpec(max_tokens=4), paired=False)["token_ids"]
+    assert a == b
+
+
+def test_postprocess_ids():
+    S = EOS + OFFSET
+    assert postprocess_ids([1005, 1006, 1007, 1008, S, 1009]) == [5, 6]
+    assert postprocess_ids([1005, 7561, 1006, 9000]) == [6]          # after SOS, drop ids >= 6561
+    assert postprocess_ids([1001, S]) == []

@@ -123,8 +123,10 @@ def test_bf16_mode_tracks_transformers_bf16():
     with torch.no_grad():
         y = m(inputs_embeds=x[None], position_ids=torch.arange(9)[None]).last_hidden_state[0].float()
     z = o.forward(x.float(), torch.arange(9), _Stream())
-    # both round every op output to bf16 but place a few roundings differently (RoPE, softmax)
-    assert (y - z).abs().max().item() <= 4 * 2 ** -7 * max(1.0, y.abs().max().item()) / 4
+    # both round every op output to bf16 but place a few roundings differently (RoPE products,
+    # softmax weights), so they agree to a few bf16 ulp (ulp = 2^-6 at the largest outputs), not bit for bit
+    d = (y - z).abs()
+    assert d.max().item() <= 6 * 2 ** -6 and d.mean().item() <= 2 ** -7
 
 
 def test_sampler_rules():

@@ -1,0 +1,112 @@
+"""ctypes binding of ``libt3hip.so`` (declarations: include/t3_hip.h).
+
+The library is the product: there is no Python or CPU fallback.  ``load()`` raises if the
+shared object is missing, and every call raises ``T3Error`` with the library's message
+when it reports a non-zero status.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from functools import lru_cache
+
+LIB_NAME = "libt3hip.so"
+ABI_VERSION = 1
+
+
+class T3Error(RuntimeError):
+    pass
+
+
+class T3Config(C.Structure):
+    _fields_ = [
+        ("n_layers", C.c_int32), ("d_model", C.c_int32), ("n_heads", C.c_int32), ("head_dim", C.c_int32),
+        ("d_ff", C.c_int32), ("text_vocab", C.c_int32), ("speech_vocab", C.c_int32),
+        ("text_pos_rows", C.c_int32), ("speech_pos_rows", C.c_int32), ("max_model_len", C.c_int32),
+        ("max_num_seqs", C.c_int32), ("cfg_paired", C.c_int32), ("max_prefill_rows", C.c_int32),
+        ("device", C.c_int32), ("use_graphs", C.c_int32), ("reserved0", C.c_int32),
+        ("cfg_scale", C.c_float), ("rms_eps", C.c_float), ("kv_pages", C.c_int64),
+    ]
+
+
+class T3Sampling(C.Structure):
+    _fields_ = [
+        ("temperature", C.c_float), ("top_p", C.c_float), ("min_p", C.c_float), ("repetition_penalty", C.c_float),
+        ("max_tokens", C.c_int32), ("stop_token", C.c_int32), ("has_seed", C.c_int32), ("reserved0", C.c_int32),
+        ("seed", C.c_uint64),
+    ]
+
+
+class T3StepStats(C.Structure):
+    _fields_ = [
+        ("prefill_requests", C.c_int32), ("prefill_rows", C.c_int32), ("decode_requests", C.c_int32),
+        ("decode_rows", C.c_int32), ("decode_ctx_tokens", C.c_int64), ("free_pages", C.c_int32),
+        ("waiting", C.c_int32), ("running", C.c_int32), ("reserved0", C.c_int32),
+        ("decode_gpu_ms", C.c_float), ("prefill_gpu_ms", C.c_float),
+    ]
+
+
+_P = C.c_void_p
+_I32P = C.POINTER(C.c_int32)
+
+# name -> (argtypes, restype); every symbol include/t3_hip.h declares
+SIGNATURES = {
+    "t3_last_error": ([], C.c_char_p),
+    "t3_abi_version": ([], C.c_int),
+    "t3_engine_create": ([C.POINTER(T3Config), C.POINTER(_P)], C.c_int),
+    "t3_engine_load_tensor": ([_P, C.c_char_p, _P, C.POINTER(C.c_int64), C.c_int32, C.c_int32], C.c_int),
+    "t3_engine_finalize": ([_P], C.c_int),
+    "t3_engine_destroy": ([_P], C.c_int),
+    "t3_engine_add_request": ([_P, C.c_int64, _I32P, C.c_int32, C.POINTER(C.c_float), C.POINTER(T3Sampling)], C.c_int),
+    "t3_engine_step": ([_P, C.POINTER(C.c_int64), _I32P, _I32P, C.c_int32, _I32P], C.c_int),
+    "t3_engine_abort": ([_P, C.c_int64], C.c_int),
+    "t3_engine_has_unfinished": ([_P], C.c_int),
+    "t3_engine_get_stats": ([_P, C.POINTER(T3StepStats)], C.c_int),
+    "t3_engine_set_timing": ([_P, C.c_int32], C.c_int),
+    "t3_engine_set_keep_logits": ([_P, C.c_int32], C.c_int),
+    "t3_engine_last_logits": ([_P, C.c_int64, C.POINTER(C.c_float)], C.c_int),
+    "t3_op_repack_weight": ([_P, _P, C.c_int32, C.c_int32, _P], C.c_int),
+    "t3_op_add_rmsnorm": ([_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_float, _P], C.c_int),
+    "t3_op_gemm": ([_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P], C.c_int),
+    "t3_op_gemm_silu": ([_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P], C.c_int),
+    "t3_op_gemm_qkv_rope": ([_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int64,
+                             C.c_int32, _P, C.c_int32, _P], C.c_int),
+    "t3_op_attn_decode": ([_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, C.c_int64, C.c_int32, _P,
+                           C.c_int32, _P], C.c_int),
+    "t3_op_attn_prefill": ([_P, _P, C.c_int32, _P, _I32P, C.c_int32, C.c_int32, _P], C.c_int),
+    "t3_op_sample_greedy": ([_P, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_float, _P, _P, C.c_int32, _P, _P, _P],
+                            C.c_int),
+}
+
+
+def lib_path() -> str:
+    return os.environ.get("T3_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", LIB_NAME)
+
+
+@lru_cache(maxsize=1)
+def load() -> C.CDLL:
+    path = lib_path()
+    if not os.path.isfile(path):
+        raise T3Error(f"{path} not found: build it with `make -C chatterbox_vllm_amd/csrc` "
+                      "(or __graft_entry__.build()); there is no fallback path")
+    lib = C.CDLL(path)
+    for name, (argtypes, restype) in SIGNATURES.items():
+        fn = getattr(lib, name)            # AttributeError here = library does not match the header
+        fn.argtypes = argtypes
+        fn.restype = restype
+    if lib.t3_abi_version() != ABI_VERSION:
+        raise T3Error(f"{path}: ABI version {lib.t3_abi_version()} != expected {ABI_VERSION}")
+    return lib
+
+
+def check(lib: C.CDLL, status: int) -> None:
+    if status != 0:
+        msg = lib.t3_last_error().decode("utf-8", "replace")
+        if status == 2:
+            raise ValueError(msg)        # request rejected (e.g. prompt longer than max_model_len)
+        raise T3Error(msg)
+
+
+def ptr(t) -> C.c_void_p:
+    """Device/host address of a torch tensor (None -> NULL)."""
+    return C.c_void_p(0 if t is None else t.data_ptr())

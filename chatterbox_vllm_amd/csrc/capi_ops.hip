@@ -1,0 +1,101 @@
+// Per-op C entry points: thin argument checks around the kernel launchers so that parity
+// tests can drive each kernel through the same C ABI the engine is shipped behind.
+#include "t3_common.h"
+#include "../../include/t3_hip.h"
+
+#include <vector>
+
+static KvView make_kv(void* pool, int64_t layer_stride, const int32_t* bt, int32_t max_pages, int H, int hd) {
+    KvView v; v.pool = static_cast<bf16_t*>(pool); v.layer_stride = layer_stride; v.block_table = bt;
+    v.max_pages = max_pages; v.H = H; v.hd = hd; return v;
+}
+
+extern "C" int t3_op_repack_weight(const void* w_dev, void* wt_dev, int32_t N, int32_t K, void* stream) {
+    T3_REQUIRE(w_dev && wt_dev, "null argument");
+    return launch_repack(static_cast<const bf16_t*>(w_dev), static_cast<bf16_t*>(wt_dev), N, K, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int t3_op_add_rmsnorm(const void* x_dev, void* res_dev, const void* w_dev, void* xn_dev, int32_t rows,
+                                 int32_t d, float eps, void* stream) {
+    T3_REQUIRE(res_dev && w_dev && xn_dev, "null argument");
+    return launch_add_rmsnorm(static_cast<const bf16_t*>(x_dev), static_cast<bf16_t*>(res_dev),
+                              static_cast<const bf16_t*>(w_dev), static_cast<bf16_t*>(xn_dev), rows, d, eps,
+                              static_cast<hipStream_t>(stream));
+}
+
+extern "C" int t3_op_gemm(const void* a_dev, const void* wt_dev, void* out_dev, int32_t M, int32_t N, int32_t K,
+                          int32_t ldc, int32_t epilogue, void* stream) {
+    T3_REQUIRE(a_dev && wt_dev && out_dev, "null argument");
+    T3_REQUIRE(epilogue == 0 || epilogue == 1, "epilogue must be 0 (store) or 1 (residual add)");
+    T3_REQUIRE(ldc >= 1, "bad ldc");
+    GemmArgs g{};
+    g.A = static_cast<const bf16_t*>(a_dev); g.lda = K; g.Wt = static_cast<const bf16_t*>(wt_dev);
+    g.C = static_cast<bf16_t*>(out_dev); g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.n_valid = ldc < N ? ldc : N;
+    return launch_gemm(epilogue == 0 ? EPI_STORE : EPI_RESID, g, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int t3_op_gemm_silu(const void* a_dev, const void* wt_dev, void* h_dev, int32_t M, int32_t F, int32_t K,
+                               void* stream) {
+    T3_REQUIRE(a_dev && wt_dev && h_dev, "null argument");
+    GemmArgs g{};
+    g.A = static_cast<const bf16_t*>(a_dev); g.lda = K; g.Wt = static_cast<const bf16_t*>(wt_dev);
+    g.C = static_cast<bf16_t*>(h_dev); g.ldc = F; g.M = M; g.N = 2 * F; g.K = K; g.n_valid = 2 * F;
+    return launch_gemm(EPI_SILU, g, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int t3_op_gemm_qkv_rope(const void* a_dev, const void* wt_dev, void* qkv_dev, int32_t M, int32_t H, int32_t hd,
+                                   int32_t K, const void* rope_dev, const int32_t* pos_dev, const int32_t* stream_dev,
+                                   void* kv_pool_dev, int64_t layer_stride_elems, int32_t layer,
+                                   const int32_t* block_table_dev, int32_t max_pages, void* stream) {
+    T3_REQUIRE(a_dev && wt_dev && qkv_dev && rope_dev && pos_dev && stream_dev && kv_pool_dev && block_table_dev,
+               "null argument");
+    GemmArgs g{};
+    g.A = static_cast<const bf16_t*>(a_dev); g.lda = K; g.Wt = static_cast<const bf16_t*>(wt_dev);
+    g.C = static_cast<bf16_t*>(qkv_dev); g.ldc = 3 * H * hd; g.M = M; g.N = 3 * H * hd; g.K = K; g.n_valid = g.N;
+    g.rope = static_cast<const bf16_t*>(rope_dev); g.pos = pos_dev; g.row_stream = stream_dev;
+    g.kv = make_kv(kv_pool_dev, layer_stride_elems, block_table_dev, max_pages, H, hd); g.layer = layer;
+    return launch_gemm(EPI_QKV_ROPE, g, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int t3_op_attn_decode(const void* qkv_dev, void* out_dev, int32_t rows, int32_t H, int32_t hd,
+                                 const int32_t* stream_dev, const int32_t* ctx_dev, const void* kv_pool_dev,
+                                 int64_t layer_stride_elems, int32_t layer, const int32_t* block_table_dev,
+                                 int32_t max_pages, void* stream) {
+    T3_REQUIRE(qkv_dev && out_dev && stream_dev && ctx_dev && kv_pool_dev && block_table_dev, "null argument");
+    const KvView kv = make_kv(const_cast<void*>(kv_pool_dev), layer_stride_elems, block_table_dev, max_pages, H, hd);
+    return launch_attn_decode(static_cast<const bf16_t*>(qkv_dev), 3 * H * hd, static_cast<bf16_t*>(out_dev), rows,
+                              stream_dev, ctx_dev, kv, layer, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int t3_op_attn_prefill(const void* qkv_dev, void* out_dev, int32_t n_seqs, const int32_t* seq_start_dev,
+                                  const int32_t* seq_start_host, int32_t H, int32_t hd, void* stream) {
+    T3_REQUIRE(qkv_dev && out_dev && seq_start_dev && seq_start_host && n_seqs >= 1, "null argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    std::vector<int32_t> tiles;
+    for (int i = 0; i < n_seqs; ++i) {
+        T3_REQUIRE(seq_start_host[i + 1] > seq_start_host[i], "empty sequence");
+        for (int q0 = 0; q0 < seq_start_host[i + 1] - seq_start_host[i]; q0 += 64) { tiles.push_back(i); tiles.push_back(q0); }
+    }
+    int32_t* d_tiles = nullptr;
+    T3_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_tiles), tiles.size() * sizeof(int32_t)));
+    T3_HIP_CHECK(hipMemcpy(d_tiles, tiles.data(), tiles.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    const int rc = launch_attn_prefill(static_cast<const bf16_t*>(qkv_dev), 3 * H * hd, static_cast<bf16_t*>(out_dev),
+                                       seq_start_dev, d_tiles, (int)tiles.size() / 2, H, hd, st);
+    const hipError_t se = hipStreamSynchronize(st);
+    (void)hipFree(d_tiles);
+    if (rc) return rc;
+    T3_HIP_CHECK(se);
+    return 0;
+}
+
+extern "C" int t3_op_sample_greedy(const void* logits_dev, int32_t ldl, int32_t vocab, const int32_t* row_c_dev,
+                                   const int32_t* row_u_dev, int32_t n, float cfg_scale, const float* rep_penalty_dev,
+                                   uint8_t* seen_dev, int32_t seen_stride, int32_t* out_tokens_dev,
+                                   float* out_logits_dev, void* stream) {
+    T3_REQUIRE(logits_dev && row_c_dev && row_u_dev && rep_penalty_dev && seen_dev && out_tokens_dev, "null argument");
+    SampleArgs s{};
+    s.logits = static_cast<const bf16_t*>(logits_dev); s.ldl = ldl; s.vocab = vocab;
+    s.row_c = row_c_dev; s.row_u = row_u_dev; s.n = n; s.cfg_scale = cfg_scale; s.rep_penalty = rep_penalty_dev;
+    s.seen = seen_dev; s.seen_stride = seen_stride; s.out_tokens = out_tokens_dev; s.out_logits = out_logits_dev;
+    return launch_sample(s, static_cast<hipStream_t>(stream));
+}

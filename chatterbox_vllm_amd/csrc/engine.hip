@@ -1,0 +1,714 @@
+// T3 decode engine: request queue, continuous-batching scheduler, KV page allocator and the
+// per-step kernel sequence, behind the C ABI of include/t3_hip.h.
+//
+// Streams and slots.  A request occupies one slot; with CFG pairing it owns two KV streams
+// (2*slot = conditional, 2*slot+1 = unconditional: same positions, the text rows of the
+// unconditional prompt are zero embeddings).  A decode step runs rows [0,B) = cond streams and
+// [B,2B) = uncond streams of the B running requests through the 30 layers.
+//
+// Step = (a) admit waiting requests while a slot, the page reservation and the prompt-row
+// budget allow, (b) prefill the admitted prompts whole and sample their first token,
+// (c) decode one token for every request that was already running, (d) one host sync, stop
+// checks, slot/page release.  Sampled ids stay on the device (last_token[slot]) and feed the
+// next step's embedding gather; the host only reads them for stop detection and output.
+//
+// KV pages hold 64 positions of one stream for all layers.  Pages are handed out lazily as a
+// stream grows; admission reserves the worst case (prompt + max_tokens, capped by
+// max_model_len) so a running request can never starve, and nothing is ever preempted.
+#include "t3_common.h"
+#include "../../include/t3_hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <deque>
+#include <map>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+static thread_local std::string g_err;
+void t3_set_error(const std::string& msg) { g_err = msg; }
+extern "C" const char* t3_last_error(void) { return g_err.c_str(); }
+extern "C" int t3_abi_version(void) { return T3_ABI_VERSION; }
+
+namespace {
+
+constexpr int kCondRows = 34;        // models/t3/t3.py:42
+constexpr int kOffset = 1000;        // models/t3/t3.py:49
+constexpr int kSOS = 6561;           // modules/t3_config.py:8
+constexpr int kCondStart = 695, kCondEnd = 696, kPrefillEnd = 697;   // t3.py:38-40
+constexpr int kSeenStride = 9216;    // >= 8194 + 1000, multiple of 4
+
+struct Request {
+    int64_t id = 0;
+    std::vector<int32_t> text;
+    std::vector<float> cond;          // [34, d]
+    t3_sampling sp{};
+    int slot = -1;
+    int prompt_len = 0;               // 34 + T + 1
+    int n_out = 0;
+    int reserve_pages = 0;            // worst-case pages per stream
+    int have_pages = 0;               // pages allocated per stream
+    bool aborted = false;
+};
+
+struct Layer {
+    bf16_t *ln1 = nullptr, *ln2 = nullptr, *wqkv = nullptr, *wo = nullptr, *wgu = nullptr, *wd = nullptr;
+};
+
+template <typename T>
+struct Pinned {
+    T* h = nullptr; T* d = nullptr; size_t n = 0;
+    int alloc(size_t count) {
+        n = count;
+        T3_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h), sizeof(T) * count));
+        T3_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d), sizeof(T) * count));
+        std::memset(h, 0, sizeof(T) * count);
+        return 0;
+    }
+    void release() { if (h) (void)hipHostFree(h); if (d) (void)hipFree(d); h = d = nullptr; }
+};
+
+}  // namespace
+
+struct t3_engine {
+    t3_config cfg{};
+    hipStream_t stream = nullptr;
+    int nstreams_per_req = 1, n_streams = 0, max_pages = 0;
+    int head_n = 0;                                     // speech vocab padded to 16
+    bool finalized = false;
+
+    // raw tensors as loaded (device), released at finalize when repacked
+    struct Raw { bf16_t* p; std::vector<int64_t> shape; };
+    std::map<std::string, Raw> raw;
+
+    bf16_t *text_emb = nullptr, *speech_emb = nullptr, *text_pos = nullptr, *speech_pos = nullptr;
+    bf16_t *rope = nullptr, *norm_w = nullptr, *head = nullptr;
+    int rope_rows = 0;
+    std::vector<Layer> layers;
+
+    // KV pool
+    bf16_t* kv_pool = nullptr;
+    int64_t n_pages = 0, layer_stride = 0;
+    std::vector<int32_t> free_pages;
+    int64_t reserved_unallocated = 0;                   // sum over running requests, in pages
+    Pinned<int32_t> block_table;                        // [n_streams][max_pages]
+    bool block_table_dirty = true;
+
+    // activations
+    int max_rows = 0;
+    bf16_t *res = nullptr, *xn = nullptr, *qkv = nullptr, *att = nullptr, *hbuf = nullptr, *logits = nullptr;
+    float* cond_buf = nullptr;                          // [max_num_seqs][34][d] fp32
+    uint8_t* seen = nullptr;                            // [max_num_seqs][kSeenStride]
+    int32_t* last_token = nullptr;                      // [max_num_seqs]
+    float* dbg_logits = nullptr;                        // [max_num_seqs][vocab+1000] when enabled
+    bool keep_logits = false;
+
+    // per-step metadata: one pinned block, one H2D copy per phase
+    struct Meta {
+        Pinned<int32_t> i32; Pinned<float> f32; Pinned<uint64_t> u64;
+        int32_t *row_stream, *row_pos, *row_ctx, *ekind, *eidx, *eaux, *row_c, *row_u, *slot, *step, *a_rows,
+                *seq_start, *tiles, *prompt_ids, *out_tokens;     // host views
+        float *rep, *temp, *top_p, *min_p;
+        uint64_t* seed;
+        size_t rows_cap = 0, req_cap = 0;
+    } dm, pm;                                            // decode / prefill
+
+    std::deque<std::unique_ptr<Request>> waiting;
+    std::vector<std::unique_ptr<Request>> slots;
+
+    std::unordered_map<int, hipGraphExec_t> graphs;
+    std::unordered_map<int, int> rows_seen;
+
+    t3_step_stats stats{};
+    bool timing = false;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+
+    KvView kvview() const {
+        KvView v; v.pool = kv_pool; v.layer_stride = layer_stride; v.block_table = block_table.d;
+        v.max_pages = max_pages; v.H = cfg.n_heads; v.hd = cfg.head_dim; return v;
+    }
+};
+
+namespace {
+
+template <typename T>
+T* carve(T*& base, size_t n) { T* p = base; base += n; return p; }
+
+int meta_alloc(t3_engine::Meta& m, size_t rows, size_t reqs, size_t prompt_ids) {
+    m.rows_cap = rows; m.req_cap = reqs;
+    const size_t tiles = rows / 32 + 4 * reqs + 64;
+    const size_t ni = rows * 6 + reqs * 5 + reqs * 2 /*a_rows*/ + (2 * reqs + 2) + 2 * tiles + prompt_ids + 64;
+    if (m.i32.alloc(ni)) return 1;
+    if (m.f32.alloc(reqs * 4 + 16)) return 1;
+    if (m.u64.alloc(reqs + 4)) return 1;
+    int32_t* p = m.i32.h;
+    m.row_stream = carve(p, rows); m.row_pos = carve(p, rows); m.row_ctx = carve(p, rows);
+    m.ekind = carve(p, rows); m.eidx = carve(p, rows); m.eaux = carve(p, rows);
+    m.row_c = carve(p, reqs); m.row_u = carve(p, reqs); m.slot = carve(p, reqs); m.step = carve(p, reqs);
+    m.out_tokens = carve(p, reqs);
+    m.a_rows = carve(p, 2 * reqs); m.seq_start = carve(p, 2 * reqs + 2); m.tiles = carve(p, 2 * tiles);
+    m.prompt_ids = carve(p, prompt_ids);
+    float* f = m.f32.h;
+    m.rep = carve(f, reqs); m.temp = carve(f, reqs); m.top_p = carve(f, reqs); m.min_p = carve(f, reqs);
+    m.seed = m.u64.h;
+    return 0;
+}
+template <typename T> T* dev_of(const Pinned<T>& p, const T* host_view) { return p.d + (host_view - p.h); }
+
+int upload(t3_engine* e, t3_engine::Meta& m) {
+    T3_HIP_CHECK(hipMemcpyAsync(m.i32.d, m.i32.h, sizeof(int32_t) * m.i32.n, hipMemcpyHostToDevice, e->stream));
+    T3_HIP_CHECK(hipMemcpyAsync(m.f32.d, m.f32.h, sizeof(float) * m.f32.n, hipMemcpyHostToDevice, e->stream));
+    T3_HIP_CHECK(hipMemcpyAsync(m.u64.d, m.u64.h, sizeof(uint64_t) * m.u64.n, hipMemcpyHostToDevice, e->stream));
+    return 0;
+}
+
+int dmalloc(bf16_t** p, size_t elems) { T3_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(p), elems * sizeof(bf16_t))); return 0; }
+
+// ---- the layer stack over `rows` rows whose embeddings are already in e->res ----------
+int run_layers(t3_engine* e, int rows, const int32_t* d_pos, const int32_t* d_stream, const int32_t* d_ctx,
+               bool prefill, const int32_t* d_seq_start, const int32_t* d_tiles, int ntiles) {
+    const t3_config& c = e->cfg;
+    const int D = c.d_model, F = c.d_ff, H = c.n_heads, hd = c.head_dim;
+    hipStream_t st = e->stream;
+    const KvView kv = e->kvview();
+    for (int li = 0; li < c.n_layers; ++li) {
+        const Layer& L = e->layers[li];
+        if (launch_add_rmsnorm(nullptr, e->res, L.ln1, e->xn, rows, D, c.rms_eps, st)) return 1;
+        GemmArgs g{};
+        g.A = e->xn; g.lda = D; g.Wt = L.wqkv; g.C = e->qkv; g.ldc = 3 * D; g.M = rows; g.N = 3 * D; g.K = D;
+        g.n_valid = 3 * D; g.rope = e->rope; g.pos = d_pos; g.row_stream = d_stream; g.kv = kv; g.layer = li;
+        if (launch_gemm(EPI_QKV_ROPE, g, st)) return 1;
+        if (prefill) {
+            if (launch_attn_prefill(e->qkv, 3 * D, e->att, d_seq_start, d_tiles, ntiles, H, hd, st)) return 1;
+        } else {
+            if (launch_attn_decode(e->qkv, 3 * D, e->att, rows, d_stream, d_ctx, kv, li, st)) return 1;
+        }
+        GemmArgs o{};
+        o.A = e->att; o.lda = D; o.Wt = L.wo; o.C = e->res; o.ldc = D; o.M = rows; o.N = D; o.K = D; o.n_valid = D;
+        if (launch_gemm(EPI_RESID, o, st)) return 1;
+        if (launch_add_rmsnorm(nullptr, e->res, L.ln2, e->xn, rows, D, c.rms_eps, st)) return 1;
+        GemmArgs u{};
+        u.A = e->xn; u.lda = D; u.Wt = L.wgu; u.C = e->hbuf; u.ldc = F; u.M = rows; u.N = 2 * F; u.K = D; u.n_valid = 2 * F;
+        if (launch_gemm(EPI_SILU, u, st)) return 1;
+        GemmArgs dn{};
+        dn.A = e->hbuf; dn.lda = F; dn.Wt = L.wd; dn.C = e->res; dn.ldc = D; dn.M = rows; dn.N = D; dn.K = F; dn.n_valid = D;
+        if (launch_gemm(EPI_RESID, dn, st)) return 1;
+    }
+    if (launch_add_rmsnorm(nullptr, e->res, e->norm_w, e->xn, rows, D, c.rms_eps, st)) return 1;
+    return 0;
+}
+
+int run_head_and_sample(t3_engine* e, t3_engine::Meta& m, int head_rows, const int32_t* d_a_rows, int n_req) {
+    const t3_config& c = e->cfg;
+    GemmArgs g{};
+    g.A = e->xn; g.lda = c.d_model; g.a_rows = d_a_rows; g.Wt = e->head; g.C = e->logits; g.ldc = e->head_n;
+    g.M = head_rows; g.N = e->head_n; g.K = c.d_model; g.n_valid = e->head_n;
+    if (launch_gemm(EPI_STORE, g, e->stream)) return 1;
+    SampleArgs s{};
+    s.logits = e->logits; s.ldl = e->head_n; s.vocab = c.speech_vocab;
+    s.row_c = dev_of(m.i32, m.row_c); s.row_u = dev_of(m.i32, m.row_u); s.slot = dev_of(m.i32, m.slot);
+    s.n = n_req; s.cfg_scale = c.cfg_scale;
+    s.rep_penalty = dev_of(m.f32, m.rep); s.temperature = dev_of(m.f32, m.temp);
+    s.top_p = dev_of(m.f32, m.top_p); s.min_p = dev_of(m.f32, m.min_p);
+    s.seed = m.u64.d; s.step = dev_of(m.i32, m.step);
+    s.seen = e->seen; s.seen_stride = kSeenStride; s.last_token = e->last_token;
+    s.out_tokens = dev_of(m.i32, m.out_tokens);
+    s.out_logits = e->keep_logits ? e->dbg_logits : nullptr;
+    return launch_sample(s, e->stream);
+}
+
+void fill_sampling(t3_engine::Meta& m, int i, const Request& r) {
+    m.slot[i] = r.slot;
+    m.step[i] = r.n_out;
+    m.rep[i] = r.sp.repetition_penalty;
+    m.temp[i] = r.sp.temperature;
+    m.top_p[i] = r.sp.top_p;
+    m.min_p[i] = r.sp.min_p;
+    m.seed[i] = r.sp.has_seed ? r.sp.seed : (0x5DEECE66DULL * (uint64_t)(r.id + 1));
+}
+
+int pages_for(int positions) { return (positions + T3_PAGE - 1) / T3_PAGE; }
+
+int grow_pages(t3_engine* e, Request& r, int positions) {
+    const int need = pages_for(positions);
+    while (r.have_pages < need) {
+        for (int u = 0; u < e->nstreams_per_req; ++u) {
+            if (e->free_pages.empty()) { t3_set_error("KV pool exhausted despite reservation"); return 1; }
+            const int32_t pg = e->free_pages.back(); e->free_pages.pop_back();
+            e->block_table.h[(size_t)(r.slot * e->nstreams_per_req + u) * e->max_pages + r.have_pages] = pg;
+        }
+        e->reserved_unallocated -= e->nstreams_per_req;
+        r.have_pages++;
+        e->block_table_dirty = true;
+    }
+    return 0;
+}
+
+void release_request(t3_engine* e, Request& r) {
+    for (int u = 0; u < e->nstreams_per_req; ++u)
+        for (int p = 0; p < r.have_pages; ++p)
+            e->free_pages.push_back(e->block_table.h[(size_t)(r.slot * e->nstreams_per_req + u) * e->max_pages + p]);
+    e->reserved_unallocated -= (int64_t)(r.reserve_pages - r.have_pages) * e->nstreams_per_req;
+}
+
+int sync_block_table(t3_engine* e) {
+    if (!e->block_table_dirty) return 0;
+    T3_HIP_CHECK(hipMemcpyAsync(e->block_table.d, e->block_table.h, sizeof(int32_t) * e->block_table.n,
+                                hipMemcpyHostToDevice, e->stream));
+    e->block_table_dirty = false;
+    return 0;
+}
+
+// ---- prefill of newly admitted requests ------------------------------------------------
+int run_prefill(t3_engine* e, const std::vector<Request*>& reqs) {
+    const t3_config& c = e->cfg;
+    t3_engine::Meta& m = e->pm;
+    const int S = e->nstreams_per_req, n = (int)reqs.size();
+    int row = 0, nseq = 0, ntiles = 0, pid = 0;
+    for (int i = 0; i < n; ++i) {
+        Request& r = *reqs[i];
+        const int T = (int)r.text.size(), P = r.prompt_len;
+        if (grow_pages(e, r, P)) return 1;
+        T3_HIP_CHECK(hipMemcpyAsync(e->cond_buf + (size_t)r.slot * kCondRows * c.d_model, r.cond.data(),
+                                    sizeof(float) * kCondRows * c.d_model, hipMemcpyHostToDevice, e->stream));
+        for (int u = 0; u < S; ++u) {
+            m.seq_start[nseq] = row;
+            for (int q0 = 0; q0 < P; q0 += 64) { m.tiles[2 * ntiles] = nseq; m.tiles[2 * ntiles + 1] = q0; ++ntiles; }
+            for (int p = 0; p < P; ++p, ++row) {
+                m.row_stream[row] = r.slot * S + u;
+                m.row_pos[row] = p;
+                m.row_ctx[row] = p + 1;
+                if (p < kCondRows) { m.ekind[row] = 0; m.eidx[row] = p; m.eaux[row] = r.slot; }
+                else if (p < kCondRows + T) {
+                    m.ekind[row] = u == 0 ? 1 : 2; m.eidx[row] = r.text[p - kCondRows]; m.eaux[row] = p - kCondRows;
+                } else { m.ekind[row] = 3; m.eidx[row] = 0; m.eaux[row] = 0; }
+            }
+            m.a_rows[u * n + i] = row - 1;                  // last prompt row of this stream
+            ++nseq;
+        }
+        m.row_c[i] = i;
+        m.row_u[i] = S == 2 ? n + i : -1;
+        fill_sampling(m, i, r);
+        // repetition-penalty set starts as the prompt ids of t3.py:229-240
+        const int base = pid;
+        m.prompt_ids[pid++] = kCondStart;
+        for (int k = 0; k < kCondRows - 2; ++k) m.prompt_ids[pid++] = r.text[0];
+        m.prompt_ids[pid++] = kCondEnd;
+        for (int k = 0; k < T; ++k) m.prompt_ids[pid++] = r.text[k];
+        m.prompt_ids[pid++] = kPrefillEnd;
+        m.step[i] = 0;
+        (void)base;
+    }
+    m.seq_start[nseq] = row;
+    const int rows = row;
+    if (sync_block_table(e)) return 1;
+    if (upload(e, m)) return 1;
+    // seen rows
+    pid = 0;
+    for (int i = 0; i < n; ++i) {
+        const int len = reqs[i]->prompt_len;
+        if (launch_seen_init(e->seen + (size_t)reqs[i]->slot * kSeenStride, kSeenStride,
+                             dev_of(m.i32, m.prompt_ids) + pid, len, e->stream)) return 1;
+        pid += len;
+    }
+    EmbedArgs ea{};
+    ea.out = e->res; ea.d = c.d_model; ea.rows = rows;
+    ea.kind = dev_of(m.i32, m.ekind); ea.idx = dev_of(m.i32, m.eidx); ea.aux = dev_of(m.i32, m.eaux);
+    ea.cond = e->cond_buf; ea.text_emb = e->text_emb; ea.text_pos = e->text_pos;
+    ea.speech_emb = e->speech_emb; ea.speech_pos = e->speech_pos; ea.last_token = e->last_token; ea.sos_id = kSOS;
+    if (launch_embed(ea, e->stream)) return 1;
+    if (run_layers(e, rows, dev_of(m.i32, m.row_pos), dev_of(m.i32, m.row_stream), dev_of(m.i32, m.row_ctx), true,
+                   dev_of(m.i32, m.seq_start), dev_of(m.i32, m.tiles), ntiles)) return 1;
+    if (run_head_and_sample(e, m, n * S, dev_of(m.i32, m.a_rows), n)) return 1;
+    e->stats.prefill_requests = n;
+    e->stats.prefill_rows = rows;
+    return 0;
+}
+
+// ---- one decode token for the running requests -------------------------------------------
+int enqueue_decode(t3_engine* e, int B) {
+    const t3_config& c = e->cfg;
+    t3_engine::Meta& m = e->dm;
+    const int rows = B * e->nstreams_per_req;
+    EmbedArgs ea{};
+    ea.out = e->res; ea.d = c.d_model; ea.rows = rows;
+    ea.kind = dev_of(m.i32, m.ekind); ea.idx = dev_of(m.i32, m.eidx); ea.aux = dev_of(m.i32, m.eaux);
+    ea.cond = e->cond_buf; ea.text_emb = e->text_emb; ea.text_pos = e->text_pos;
+    ea.speech_emb = e->speech_emb; ea.speech_pos = e->speech_pos; ea.last_token = e->last_token; ea.sos_id = kSOS;
+    if (launch_embed(ea, e->stream)) return 1;
+    if (run_layers(e, rows, dev_of(m.i32, m.row_pos), dev_of(m.i32, m.row_stream), dev_of(m.i32, m.row_ctx), false,
+                   nullptr, nullptr, 0)) return 1;
+    return run_head_and_sample(e, m, rows, nullptr, B);
+}
+
+int run_decode(t3_engine* e, const std::vector<Request*>& reqs) {
+    t3_engine::Meta& m = e->dm;
+    const int S = e->nstreams_per_req, B = (int)reqs.size();
+    int64_t ctx_total = 0;
+    for (int i = 0; i < B; ++i) {
+        Request& r = *reqs[i];
+        const int pos = r.prompt_len + r.n_out - 1;          // position of the token fed this step
+        if (grow_pages(e, r, pos + 1)) return 1;
+        for (int u = 0; u < S; ++u) {
+            const int row = u * B + i;
+            m.row_stream[row] = r.slot * S + u;
+            m.row_pos[row] = pos;
+            m.row_ctx[row] = pos + 1;
+            m.ekind[row] = 4; m.eidx[row] = r.slot; m.eaux[row] = 0;
+            ctx_total += pos + 1;
+        }
+        m.row_c[i] = i;
+        m.row_u[i] = S == 2 ? B + i : -1;
+        fill_sampling(m, i, r);
+    }
+    if (sync_block_table(e)) return 1;
+    if (upload(e, m)) return 1;
+    const bool graphs = e->cfg.use_graphs && !e->keep_logits;
+    if (graphs && e->rows_seen[B]++ >= 1) {
+        auto it = e->graphs.find(B);
+        if (it == e->graphs.end()) {
+            hipGraph_t graph = nullptr;
+            T3_HIP_CHECK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+            const int rc = enqueue_decode(e, B);
+            const hipError_t ce = hipStreamEndCapture(e->stream, &graph);
+            if (rc) return 1;
+            T3_HIP_CHECK(ce);
+            hipGraphExec_t exec = nullptr;
+            T3_HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+            T3_HIP_CHECK(hipGraphDestroy(graph));
+            it = e->graphs.emplace(B, exec).first;
+        }
+        T3_HIP_CHECK(hipGraphLaunch(it->second, e->stream));
+    } else {
+        if (enqueue_decode(e, B)) return 1;
+    }
+    e->stats.decode_requests = B;
+    e->stats.decode_rows = B * S;
+    e->stats.decode_ctx_tokens = ctx_total;
+    return 0;
+}
+
+int find_tensor(t3_engine* e, const std::string& name, int64_t d0, int64_t d1, bf16_t** out) {
+    auto it = e->raw.find(name);
+    if (it == e->raw.end()) { t3_set_error("missing tensor: " + name); return 1; }
+    const auto& sh = it->second.shape;
+    const bool ok = d1 < 0 ? (sh.size() == 1 && sh[0] == d0) : (sh.size() == 2 && sh[0] == d0 && sh[1] == d1);
+    if (!ok) { t3_set_error("bad shape for tensor: " + name); return 1; }
+    *out = it->second.p;
+    return 0;
+}
+
+}  // namespace
+
+// =========================================================================================
+extern "C" int t3_engine_create(const t3_config* cfg, t3_engine** out) {
+    T3_REQUIRE(cfg && out, "null argument");
+    T3_REQUIRE(cfg->d_model == 1024 && cfg->head_dim == 64 && cfg->n_heads * cfg->head_dim == cfg->d_model,
+               "engine is built for d_model 1024 = 16 heads x 64");
+    T3_REQUIRE(cfg->d_ff == 4096, "engine is built for d_ff 4096");
+    T3_REQUIRE(cfg->n_layers >= 1 && cfg->max_num_seqs >= 1 && cfg->max_model_len >= kCondRows + 3, "bad sizes");
+    T3_REQUIRE(cfg->speech_vocab + kOffset <= kSeenStride, "speech vocab too large");
+    T3_HIP_CHECK(hipSetDevice(cfg->device));
+    std::unique_ptr<t3_engine> e(new t3_engine());
+    e->cfg = *cfg;
+    if (e->cfg.max_prefill_rows < e->cfg.max_model_len) e->cfg.max_prefill_rows = e->cfg.max_model_len;
+    const t3_config& c = e->cfg;
+    e->nstreams_per_req = c.cfg_paired ? 2 : 1;
+    e->n_streams = c.max_num_seqs * e->nstreams_per_req;
+    e->max_pages = pages_for(c.max_model_len);
+    e->head_n = (c.speech_vocab + 15) / 16 * 16;
+    T3_HIP_CHECK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    e->layers.resize(c.n_layers);
+    e->slots.resize(c.max_num_seqs);
+
+    // KV pool
+    e->n_pages = c.kv_pages > 0 ? c.kv_pages : (int64_t)e->n_streams * e->max_pages;
+    T3_REQUIRE(e->n_pages >= (int64_t)e->nstreams_per_req * e->max_pages, "kv_pages cannot hold one full request");
+    const int64_t page_elems = 2LL * c.n_heads * T3_PAGE * c.head_dim;
+    e->layer_stride = e->n_pages * page_elems;
+    const size_t pool_elems = (size_t)e->layer_stride * c.n_layers;
+    if (dmalloc(&e->kv_pool, pool_elems)) return 1;
+    T3_HIP_CHECK(hipMemsetAsync(e->kv_pool, 0, pool_elems * sizeof(bf16_t), e->stream));
+    e->free_pages.reserve(e->n_pages);
+    for (int64_t p = e->n_pages - 1; p >= 0; --p) e->free_pages.push_back((int32_t)p);
+    if (e->block_table.alloc((size_t)e->n_streams * e->max_pages)) return 1;
+
+    // activations
+    const int prefill_rows = c.max_prefill_rows * e->nstreams_per_req;
+    e->max_rows = std::max(prefill_rows, e->n_streams);
+    const size_t R = e->max_rows;
+    if (dmalloc(&e->res, R * c.d_model) || dmalloc(&e->xn, R * c.d_model) || dmalloc(&e->qkv, R * 3 * c.d_model) ||
+        dmalloc(&e->att, R * c.d_model) || dmalloc(&e->hbuf, R * c.d_ff) ||
+        dmalloc(&e->logits, (size_t)e->n_streams * e->head_n)) return 1;
+    T3_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->cond_buf), sizeof(float) * c.max_num_seqs * kCondRows * c.d_model));
+    T3_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->seen), (size_t)c.max_num_seqs * kSeenStride));
+    T3_HIP_CHECK(hipMemsetAsync(e->seen, 0, (size_t)c.max_num_seqs * kSeenStride, e->stream));
+    T3_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->last_token), sizeof(int32_t) * c.max_num_seqs));
+    T3_HIP_CHECK(hipMemsetAsync(e->last_token, 0, sizeof(int32_t) * c.max_num_seqs, e->stream));
+    T3_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->dbg_logits),
+                           sizeof(float) * c.max_num_seqs * (size_t)(c.speech_vocab + kOffset)));
+    if (meta_alloc(e->dm, e->n_streams, c.max_num_seqs, 16)) return 1;
+    if (meta_alloc(e->pm, prefill_rows, c.max_num_seqs, (size_t)c.max_prefill_rows + (size_t)c.max_num_seqs * 64)) return 1;
+    for (auto& ev : e->ev) T3_HIP_CHECK(hipEventCreate(&ev));
+    T3_HIP_CHECK(hipStreamSynchronize(e->stream));
+    *out = e.release();
+    return 0;
+}
+
+extern "C" int t3_engine_load_tensor(t3_engine* e, const char* name, const void* data, const int64_t* shape,
+                                     int32_t ndim, int32_t dtype) {
+    T3_REQUIRE(e && name && data && shape, "null argument");
+    T3_REQUIRE(!e->finalized, "engine already finalized");
+    T3_REQUIRE(dtype == 0, "only bf16 (dtype 0) tensors are accepted");
+    T3_REQUIRE(ndim == 1 || ndim == 2, "tensors must be 1-D or 2-D");
+    T3_HIP_CHECK(hipSetDevice(e->cfg.device));
+    size_t n = 1;
+    std::vector<int64_t> sh(shape, shape + ndim);
+    for (auto v : sh) { T3_REQUIRE(v > 0, "bad shape"); n *= (size_t)v; }
+    bf16_t* p = nullptr;
+    if (dmalloc(&p, n)) return 1;
+    T3_HIP_CHECK(hipMemcpy(p, data, n * sizeof(bf16_t), hipMemcpyHostToDevice));
+    auto it = e->raw.find(name);
+    if (it != e->raw.end()) { (void)hipFree(it->second.p); e->raw.erase(it); }
+    e->raw[name] = t3_engine::Raw{p, sh};
+    return 0;
+}
+
+extern "C" int t3_engine_finalize(t3_engine* e) {
+    T3_REQUIRE(e && !e->finalized, "bad engine state");
+    T3_HIP_CHECK(hipSetDevice(e->cfg.device));
+    const t3_config& c = e->cfg;
+    const int D = c.d_model, F = c.d_ff;
+    hipStream_t st = e->stream;
+    if (find_tensor(e, "text_emb.weight", c.text_vocab, D, &e->text_emb)) return 1;
+    if (find_tensor(e, "speech_emb.weight", c.speech_vocab, D, &e->speech_emb)) return 1;
+    if (find_tensor(e, "text_pos_emb.emb.weight", c.text_pos_rows, D, &e->text_pos)) return 1;
+    if (find_tensor(e, "speech_pos_emb.emb.weight", c.speech_pos_rows, D, &e->speech_pos)) return 1;
+    if (find_tensor(e, "tfmr.norm.weight", D, -1, &e->norm_w)) return 1;
+    {
+        auto it = e->raw.find("rope.cos_sin");
+        T3_REQUIRE(it != e->raw.end(), "missing tensor: rope.cos_sin");
+        T3_REQUIRE(it->second.shape.size() == 2 && it->second.shape[1] == c.head_dim &&
+                   it->second.shape[0] >= c.max_model_len, "rope.cos_sin must be [>= max_model_len, head_dim]");
+        e->rope = it->second.p; e->rope_rows = (int)it->second.shape[0];
+    }
+    std::vector<std::string> consumed;
+    // speech head, zero-padded to a multiple of 16 rows, tiled
+    {
+        bf16_t* hw = nullptr;
+        if (find_tensor(e, "speech_head.weight", c.speech_vocab, D, &hw)) return 1;
+        bf16_t* padded = nullptr;
+        if (dmalloc(&padded, (size_t)e->head_n * D) || dmalloc(&e->head, (size_t)e->head_n * D)) return 1;
+        T3_HIP_CHECK(hipMemsetAsync(padded, 0, (size_t)e->head_n * D * sizeof(bf16_t), st));
+        T3_HIP_CHECK(hipMemcpyAsync(padded, hw, (size_t)c.speech_vocab * D * sizeof(bf16_t), hipMemcpyDeviceToDevice, st));
+        if (launch_repack(padded, e->head, e->head_n, D, st)) return 1;
+        T3_HIP_CHECK(hipStreamSynchronize(st));
+        (void)hipFree(padded);
+        consumed.push_back("speech_head.weight");
+    }
+    bf16_t* cat = nullptr;
+    if (dmalloc(&cat, (size_t)2 * F * D)) return 1;       // staging for fused [q|k|v] and [gate|up]
+    for (int li = 0; li < c.n_layers; ++li) {
+        Layer& L = e->layers[li];
+        const std::string p = "tfmr.layers." + std::to_string(li) + ".";
+        bf16_t *q, *k, *v, *o, *g, *u, *d;
+        if (find_tensor(e, p + "input_layernorm.weight", D, -1, &L.ln1)) return 1;
+        if (find_tensor(e, p + "post_attention_layernorm.weight", D, -1, &L.ln2)) return 1;
+        if (find_tensor(e, p + "self_attn.q_proj.weight", D, D, &q) || find_tensor(e, p + "self_attn.k_proj.weight", D, D, &k) ||
+            find_tensor(e, p + "self_attn.v_proj.weight", D, D, &v) || find_tensor(e, p + "self_attn.o_proj.weight", D, D, &o) ||
+            find_tensor(e, p + "mlp.gate_proj.weight", F, D, &g) || find_tensor(e, p + "mlp.up_proj.weight", F, D, &u) ||
+            find_tensor(e, p + "mlp.down_proj.weight", D, F, &d)) return 1;
+        if (dmalloc(&L.wqkv, (size_t)3 * D * D) || dmalloc(&L.wo, (size_t)D * D) || dmalloc(&L.wgu, (size_t)2 * F * D) ||
+            dmalloc(&L.wd, (size_t)D * F)) return 1;
+        const size_t dd = (size_t)D * D * sizeof(bf16_t), fd = (size_t)F * D * sizeof(bf16_t);
+        T3_HIP_CHECK(hipMemcpyAsync(cat, q, dd, hipMemcpyDeviceToDevice, st));
+        T3_HIP_CHECK(hipMemcpyAsync(cat + (size_t)D * D, k, dd, hipMemcpyDeviceToDevice, st));
+        T3_HIP_CHECK(hipMemcpyAsync(cat + (size_t)2 * D * D, v, dd, hipMemcpyDeviceToDevice, st));
+        if (launch_repack(cat, L.wqkv, 3 * D, D, st)) return 1;
+        if (launch_repack(o, L.wo, D, D, st)) return 1;
+        T3_HIP_CHECK(hipMemcpyAsync(cat, g, fd, hipMemcpyDeviceToDevice, st));
+        T3_HIP_CHECK(hipMemcpyAsync(cat + (size_t)F * D, u, fd, hipMemcpyDeviceToDevice, st));
+        if (launch_repack(cat, L.wgu, 2 * F, D, st)) return 1;
+        if (launch_repack(d, L.wd, D, F, st)) return 1;
+        for (const char* s : {"self_attn.q_proj.weight", "self_attn.k_proj.weight", "self_attn.v_proj.weight",
+                              "self_attn.o_proj.weight", "mlp.gate_proj.weight", "mlp.up_proj.weight", "mlp.down_proj.weight"})
+            consumed.push_back(p + s);
+    }
+    T3_HIP_CHECK(hipStreamSynchronize(st));
+    (void)hipFree(cat);
+    for (const auto& nme : consumed) {
+        auto it = e->raw.find(nme);
+        if (it != e->raw.end()) { (void)hipFree(it->second.p); e->raw.erase(it); }
+    }
+    e->finalized = true;
+    return 0;
+}
+
+extern "C" int t3_engine_destroy(t3_engine* e) {
+    if (!e) return 0;
+    (void)hipSetDevice(e->cfg.device);
+    (void)hipStreamSynchronize(e->stream);
+    for (auto& kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
+    for (auto& kv : e->raw) (void)hipFree(kv.second.p);
+    for (auto& L : e->layers) { (void)hipFree(L.wqkv); (void)hipFree(L.wo); (void)hipFree(L.wgu); (void)hipFree(L.wd); }
+    (void)hipFree(e->head); (void)hipFree(e->kv_pool);
+    (void)hipFree(e->res); (void)hipFree(e->xn); (void)hipFree(e->qkv); (void)hipFree(e->att); (void)hipFree(e->hbuf);
+    (void)hipFree(e->logits); (void)hipFree(e->cond_buf); (void)hipFree(e->seen); (void)hipFree(e->last_token);
+    (void)hipFree(e->dbg_logits);
+    e->block_table.release();
+    for (auto* m : {&e->dm, &e->pm}) { m->i32.release(); m->f32.release(); m->u64.release(); }
+    for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
+    (void)hipStreamDestroy(e->stream);
+    delete e;
+    return 0;
+}
+
+extern "C" int t3_engine_add_request(t3_engine* e, int64_t req_id, const int32_t* text_ids, int32_t n_text,
+                                     const float* cond, const t3_sampling* sp) {
+    T3_REQUIRE(e && text_ids && cond && sp, "null argument");
+    T3_REQUIRE(e->finalized, "engine not finalized");
+    const t3_config& c = e->cfg;
+    T3_REQUIRE(n_text >= 1, "empty prompt");
+    T3_REQUIRE(n_text <= c.text_pos_rows, "prompt longer than the text position table");
+    const int P = kCondRows + n_text + 1;
+    if (P > c.max_model_len) {
+        t3_set_error("prompt of " + std::to_string(P) + " tokens exceeds max_model_len=" + std::to_string(c.max_model_len));
+        return 2;
+    }
+    T3_REQUIRE(P <= c.max_prefill_rows, "prompt longer than max_prefill_rows");
+    for (int i = 0; i < n_text; ++i)
+        T3_REQUIRE(text_ids[i] >= 0 && text_ids[i] < c.text_vocab, "text id outside the text vocabulary");
+    T3_REQUIRE(sp->max_tokens >= 1 && sp->repetition_penalty > 0.f, "bad sampling parameters");
+    for (auto& w : e->waiting) T3_REQUIRE(w->id != req_id, "duplicate request id");
+    for (auto& s : e->slots) T3_REQUIRE(!s || s->id != req_id, "duplicate request id");
+    std::unique_ptr<Request> r(new Request());
+    r->id = req_id;
+    r->text.assign(text_ids, text_ids + n_text);
+    r->cond.assign(cond, cond + (size_t)kCondRows * c.d_model);
+    r->sp = *sp;
+    r->prompt_len = P;
+    r->reserve_pages = pages_for(std::min(P + sp->max_tokens, c.max_model_len));
+    e->waiting.push_back(std::move(r));
+    return 0;
+}
+
+extern "C" int t3_engine_abort(t3_engine* e, int64_t req_id) {
+    T3_REQUIRE(e, "null argument");
+    for (auto it = e->waiting.begin(); it != e->waiting.end(); ++it)
+        if ((*it)->id == req_id) { e->waiting.erase(it); return 0; }
+    for (auto& s : e->slots)
+        if (s && s->id == req_id) { release_request(e, *s); s.reset(); return 0; }
+    t3_set_error("abort: unknown request id");
+    return 1;
+}
+
+extern "C" int t3_engine_has_unfinished(t3_engine* e) {
+    if (!e) return 0;
+    if (!e->waiting.empty()) return 1;
+    for (auto& s : e->slots) if (s) return 1;
+    return 0;
+}
+
+extern "C" int t3_engine_get_stats(t3_engine* e, t3_step_stats* out) {
+    T3_REQUIRE(e && out, "null argument");
+    *out = e->stats;
+    return 0;
+}
+
+extern "C" int t3_engine_set_timing(t3_engine* e, int32_t on) {
+    T3_REQUIRE(e, "null argument");
+    e->timing = on != 0;
+    return 0;
+}
+
+extern "C" int t3_engine_set_keep_logits(t3_engine* e, int32_t on) {
+    T3_REQUIRE(e, "null argument");
+    e->keep_logits = on != 0;
+    return 0;
+}
+
+extern "C" int t3_engine_last_logits(t3_engine* e, int64_t req_id, float* out) {
+    T3_REQUIRE(e && out, "null argument");
+    T3_REQUIRE(e->keep_logits, "logit taps are off (t3_engine_set_keep_logits)");
+    for (auto& s : e->slots)
+        if (s && s->id == req_id) {
+            const size_t n = (size_t)e->cfg.speech_vocab + kOffset;
+            T3_HIP_CHECK(hipMemcpy(out, e->dbg_logits + (size_t)s->slot * n, n * sizeof(float), hipMemcpyDeviceToHost));
+            return 0;
+        }
+    t3_set_error("last_logits: request is not running");
+    return 1;
+}
+
+extern "C" int t3_engine_step(t3_engine* e, int64_t* out_req_ids, int32_t* out_tokens, int32_t* out_finished,
+                              int32_t cap, int32_t* n_out) {
+    T3_REQUIRE(e && out_req_ids && out_tokens && out_finished && n_out, "null argument");
+    T3_REQUIRE(e->finalized, "engine not finalized");
+    T3_HIP_CHECK(hipSetDevice(e->cfg.device));
+    const t3_config& c = e->cfg;
+    *n_out = 0;
+    std::memset(&e->stats, 0, sizeof(e->stats));
+
+    // requests that were running before this step decode; new ones prefill
+    std::vector<Request*> running, admitted;
+    for (auto& s : e->slots) if (s) running.push_back(s.get());
+    int row_budget = c.max_prefill_rows;
+    while (!e->waiting.empty()) {
+        Request& r = *e->waiting.front();
+        int slot = -1;
+        for (int i = 0; i < c.max_num_seqs; ++i) if (!e->slots[i]) { slot = i; break; }
+        if (slot < 0) break;
+        const int64_t need = (int64_t)r.reserve_pages * e->nstreams_per_req;
+        if ((int64_t)e->free_pages.size() - e->reserved_unallocated < need) break;
+        if (r.prompt_len > row_budget) break;
+        row_budget -= r.prompt_len;
+        e->reserved_unallocated += need;
+        r.slot = slot;
+        admitted.push_back(&r);
+        e->slots[slot] = std::move(e->waiting.front());
+        e->waiting.pop_front();
+    }
+    T3_REQUIRE((int)(running.size() + admitted.size()) <= cap, "output arrays too small");
+
+    if (!admitted.empty()) {
+        if (e->timing) T3_HIP_CHECK(hipEventRecord(e->ev[0], e->stream));
+        if (run_prefill(e, admitted)) return 1;
+        if (e->timing) T3_HIP_CHECK(hipEventRecord(e->ev[1], e->stream));
+        T3_HIP_CHECK(hipMemcpyAsync(e->pm.out_tokens, dev_of(e->pm.i32, e->pm.out_tokens), sizeof(int32_t) * admitted.size(),
+                                    hipMemcpyDeviceToHost, e->stream));
+    }
+    if (!running.empty()) {
+        if (e->timing) T3_HIP_CHECK(hipEventRecord(e->ev[2], e->stream));
+        if (run_decode(e, running)) return 1;
+        if (e->timing) T3_HIP_CHECK(hipEventRecord(e->ev[3], e->stream));
+        T3_HIP_CHECK(hipMemcpyAsync(e->dm.out_tokens, dev_of(e->dm.i32, e->dm.out_tokens), sizeof(int32_t) * running.size(),
+                                    hipMemcpyDeviceToHost, e->stream));
+    }
+    T3_HIP_CHECK(hipStreamSynchronize(e->stream));
+    if (e->timing) {
+        if (!admitted.empty()) T3_HIP_CHECK(hipEventElapsedTime(&e->stats.prefill_gpu_ms, e->ev[0], e->ev[1]));
+        if (!running.empty()) T3_HIP_CHECK(hipEventElapsedTime(&e->stats.decode_gpu_ms, e->ev[2], e->ev[3]));
+    }
+
+    int k = 0;
+    auto account = [&](Request* r, int32_t tok) {
+        r->n_out++;
+        int fin = 0;
+        if (tok == r->sp.stop_token) fin = 1;
+        else if (r->n_out >= r->sp.max_tokens || r->prompt_len + r->n_out >= c.max_model_len) fin = 2;
+        out_req_ids[k] = r->id; out_tokens[k] = tok; out_finished[k] = fin; ++k;
+        if (fin) { release_request(e, *r); e->slots[r->slot].reset(); }
+    };
+    for (size_t i = 0; i < admitted.size(); ++i) account(admitted[i], e->pm.out_tokens[i]);
+    for (size_t i = 0; i < running.size(); ++i) account(running[i], e->dm.out_tokens[i]);
+    *n_out = k;
+    e->stats.free_pages = (int32_t)e->free_pages.size();
+    e->stats.waiting = (int32_t)e->waiting.size();
+    int run = 0;
+    for (auto& s : e->slots) if (s) ++run;
+    e->stats.running = run;
+    return 0;
+}

@@ -1,0 +1,252 @@
+// Weight-streaming GEMM for the T3 backbone on gfx950:  C[M,N] = A[M,K] * W[N,K]^T.
+//
+// Decode steps have few rows (M = 1 .. 2*max_num_seqs), so every projection is bound by
+// streaming W from HBM exactly once.  W is therefore stored pre-tiled in the order one
+// MFMA operand fragment is consumed: tile (nb, kb) = rows nb*16..+16, cols kb*32..+32 of
+// W, 1 KiB, element (lane*8 + j) = W[nb*16 + (lane&15)][kb*32 + 8*(lane>>4) + j].  One
+// global_load_dwordx4 per lane fetches a whole tile as 1 KiB of contiguous memory and the
+// registers are the v_mfma_f32_16x16x32_bf16 operand as loaded - no LDS, no shuffles.
+//
+// A workgroup owns NB n-blocks (16 output columns each) over the whole K: its KW waves each
+// take KT consecutive k-tiles (KW*KT*32 == K), accumulate NB x MT 16x16 tiles (MT = row tiles
+// of 16) and the partial tiles are summed through LDS in wave order 0..KW-1.  That order, and
+// the k order inside a wave, do not depend on M or on which rows share the launch, so a row's
+// result is bit-identical for every batch composition.  Prompt rows (M > 128) run the same
+// kernel over row groups of 128 (blockIdx.y); W then comes from L2 / Infinity Cache.
+//
+// The MFMA is issued as D = Wtile(16 n x 32 k) * Atile^T(32 k x 16 rows): lane l ends up with
+// 4 consecutive output columns n = 4*(l>>4)+0..3 of row (l&15), i.e. one 8-byte bf16 store.
+//
+// Epilogues (one rounding to bf16 after the fp32 accumulation, then):
+//   EPI_STORE     C = bf16(acc)
+//   EPI_RESID     C = bf16(bf16(acc) + C)                        (o_proj / down_proj + residual)
+//   EPI_SILU      h = bf16(bf16(silu(g)) * u), g/u = n-blocks b and b + F/16   (gate_up_proj)
+//   EPI_QKV_ROPE  half-split RoPE on q,k (n-blocks j and j+32 columns of one head), store the
+//                 rotated q|k|v row and scatter k, v into the paged KV cache.
+#include "t3_common.h"
+
+template <int NB, int MT, int KW, int KT, int EPI>
+__global__ __launch_bounds__(KW * 64) void gemm_stream_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float red_raw[];
+    f32x4* red = reinterpret_cast<f32x4*>(red_raw);
+    constexpr int NT = NB * MT;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.x;
+    const int m0 = blockIdx.y * (MT * 16);
+    const int ktiles = a.K >> 5;
+
+    int nbi[NB];
+    int H = 0, region = 0, head = 0, half = 0;
+    if constexpr (EPI == EPI_SILU) {
+        nbi[0] = b;
+        nbi[1] = b + (a.N >> 5);                  // up rows start at F = N/2 -> F/16 n-blocks
+    } else if constexpr (EPI == EPI_QKV_ROPE) {
+        H = a.kv.H;
+        region = b / (2 * H);
+        const int i = b - region * 2 * H;
+        head = i >> 1;
+        half = i & 1;
+        if (region < 2) { nbi[0] = region * 4 * H + head * 4 + half; nbi[1] = nbi[0] + 2; }
+        else            { nbi[0] = 2 * 4 * H + head * 4 + half * 2;  nbi[1] = nbi[0] + 1; }
+    } else {
+        nbi[0] = b;
+    }
+
+    f32x4 acc[NB][MT];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[nb][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int kt0 = w * KT;
+    // weight fragments: the HBM stream, issued first
+    bf16x8 wf[NB][KT];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const bf16x8* wp = reinterpret_cast<const bf16x8*>(a.Wt) + ((size_t)nbi[nb] * ktiles + kt0) * 64 + lane;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) wf[nb][kt] = __builtin_nontemporal_load(wp + kt * 64);
+    }
+    // activation fragments (L2-resident)
+    const bf16_t* arow[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        int r = m0 + mt * 16 + (lane & 15);
+        r = r < a.M ? r : a.M - 1;
+        if (a.a_rows) r = a.a_rows[r];
+        arow[mt] = a.A + (size_t)r * a.lda + kt0 * 32 + 8 * (lane >> 4);
+    }
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+        bf16x8 af[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const bf16x8*>(arow[mt] + kt * 32);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                acc[nb][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb][kt], af[mt], acc[nb][mt], 0, 0, 0);
+    }
+
+    // cross-wave K reduction through LDS, fixed order
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) red[(w * NT + nb * MT + mt) * 64 + lane] = acc[nb][mt];
+    __syncthreads();
+
+    for (int mt = w; mt < MT; mt += KW) {
+        f32x4 s[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            s[nb] = red[(nb * MT + mt) * 64 + lane];
+#pragma unroll
+            for (int w2 = 1; w2 < KW; ++w2) s[nb] += red[(w2 * NT + nb * MT + mt) * 64 + lane];
+        }
+        const int r = m0 + mt * 16 + (lane & 15);
+        if (r >= a.M) continue;
+        const int nl = 4 * (lane >> 4);
+
+        if constexpr (EPI == EPI_STORE || EPI == EPI_RESID) {
+            const int n = nbi[0] * 16 + nl;
+            bf16_t* cp = a.C + (size_t)r * a.ldc + n;
+            float v[4] = {rbf(s[0][0]), rbf(s[0][1]), rbf(s[0][2]), rbf(s[0][3])};
+            const bool vec = ((a.ldc & 3) == 0) && (n + 3 < a.n_valid);
+            if constexpr (EPI == EPI_RESID) {
+                if (vec) {
+                    u32x2 o = *reinterpret_cast<const u32x2*>(cp);
+                    v[0] += bf_lo(o[0]); v[1] += bf_hi(o[0]); v[2] += bf_lo(o[1]); v[3] += bf_hi(o[1]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) if (n + i < a.n_valid) v[i] += bf2f(cp[i]);
+                }
+            }
+            if (vec) {
+                u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+                *reinterpret_cast<u32x2*>(cp) = o;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) if (n + i < a.n_valid) cp[i] = f2bf(v[i]);
+            }
+        } else if constexpr (EPI == EPI_SILU) {
+            const int F = a.N >> 1;
+            float hv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float g = rbf(s[0][i]), u = rbf(s[1][i]);
+                const float sg = rbf(g / (1.0f + expf(-g)));
+                hv[i] = sg * u;
+            }
+            u32x2 o = {pack_bf2(hv[0], hv[1]), pack_bf2(hv[2], hv[3])};
+            *reinterpret_cast<u32x2*>(a.C + (size_t)r * F + b * 16 + nl) = o;
+        } else {   // EPI_QKV_ROPE
+            const int hd = a.kv.hd;                       // 64
+            const int D = H * hd;
+            float x[4], y[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { x[i] = rbf(s[0][i]); y[i] = rbf(s[1][i]); }
+            const int pos = a.pos[r];
+            int c0, c1;                                   // column inside the head of x[0], y[0]
+            if (region < 2) {
+                c0 = half * 16 + nl; c1 = c0 + 32;
+                const bf16_t* tb = a.rope + (size_t)pos * hd;
+                const u32x2 cs = *reinterpret_cast<const u32x2*>(tb + c0);
+                const u32x2 sn = *reinterpret_cast<const u32x2*>(tb + 32 + c0);
+                const float c[4] = {bf_lo(cs[0]), bf_hi(cs[0]), bf_lo(cs[1]), bf_hi(cs[1])};
+                const float sv[4] = {bf_lo(sn[0]), bf_hi(sn[0]), bf_lo(sn[1]), bf_hi(sn[1])};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float xr = x[i] * c[i] - y[i] * sv[i];
+                    const float yr = y[i] * c[i] + x[i] * sv[i];
+                    x[i] = xr; y[i] = yr;
+                }
+            } else {
+                c0 = half * 32 + nl; c1 = c0 + 16;
+            }
+            const u32x2 ox = {pack_bf2(x[0], x[1]), pack_bf2(x[2], x[3])};
+            const u32x2 oy = {pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3])};
+            bf16_t* qrow = a.C + (size_t)r * a.ldc + region * D + head * hd;
+            *reinterpret_cast<u32x2*>(qrow + c0) = ox;
+            *reinterpret_cast<u32x2*>(qrow + c1) = oy;
+            if (region >= 1) {
+                const int st = a.row_stream[r];
+                if (st >= 0) {
+                    const int page = a.kv.block_table[(size_t)st * a.kv.max_pages + (pos >> 6)];
+                    bf16_t* base = a.kv.pool + (size_t)a.layer * a.kv.layer_stride +
+                                   ((size_t)page * 2 + (region - 1)) * ((size_t)H * T3_PAGE * hd) +
+                                   ((size_t)head * T3_PAGE + (pos & 63)) * hd;
+                    *reinterpret_cast<u32x2*>(base + c0) = ox;
+                    *reinterpret_cast<u32x2*>(base + c1) = oy;
+                }
+            }
+        }
+    }
+}
+
+// Tile repack: one thread per 8 consecutive k of one W row.
+__global__ void repack_kernel(const bf16_t* __restrict__ w, bf16_t* __restrict__ wt, int N, int K) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int k8 = K >> 3;
+    if (t >= (size_t)N * k8) return;
+    const int n = (int)(t / k8), kc = (int)(t % k8);
+    const int nb = n >> 4, nr = n & 15, kb = kc >> 2, q = kc & 3;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(w + (size_t)n * K + kc * 8);
+    const size_t dst = (((size_t)nb * (K >> 5) + kb) * 64 + (q * 16 + nr)) * 8;
+    *reinterpret_cast<u32x4*>(wt + dst) = v;
+}
+
+int launch_repack(const bf16_t* w, bf16_t* wt, int N, int K, hipStream_t st) {
+    T3_REQUIRE(N % 16 == 0 && K % 32 == 0, "repack: N must be a multiple of 16 and K of 32");
+    const size_t n = (size_t)N * (K / 8);
+    hipLaunchKernelGGL(repack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, wt, N, K);
+    T3_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+template <int NB, int MT, int KW, int KT, int EPI>
+static int launch_one(const GemmArgs& a, int nblocks, hipStream_t st) {
+    constexpr size_t lds = (size_t)KW * NB * MT * 64 * sizeof(f32x4);
+    static bool attr_set = false;
+    if (!attr_set) {
+        T3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_stream_kernel<NB, MT, KW, KT, EPI>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const int groups = (a.M + MT * 16 - 1) / (MT * 16);
+    hipLaunchKernelGGL((gemm_stream_kernel<NB, MT, KW, KT, EPI>), dim3(nblocks, groups), dim3(KW * 64), lds, st, a);
+    T3_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+template <int NB, int KW, int KT, int EPI>
+static int launch_mt(const GemmArgs& a, int nblocks, hipStream_t st) {
+    if (a.M <= 16) return launch_one<NB, 1, KW, KT, EPI>(a, nblocks, st);
+    if (a.M <= 32) return launch_one<NB, 2, KW, KT, EPI>(a, nblocks, st);
+    if (a.M <= 64) return launch_one<NB, 4, KW, KT, EPI>(a, nblocks, st);
+    return launch_one<NB, 8, KW, KT, EPI>(a, nblocks, st);
+}
+
+int launch_gemm(int epi, const GemmArgs& a, hipStream_t st) {
+    T3_REQUIRE(a.M >= 1, "gemm: no rows");
+    T3_REQUIRE(a.N % 16 == 0, "gemm: N must be a multiple of 16");
+    T3_REQUIRE(a.lda % 8 == 0, "gemm: lda must be a multiple of 8");
+    T3_REQUIRE(a.K == 1024 || a.K == 4096, "gemm: K must be 1024 or 4096");
+    switch (epi) {
+        case EPI_STORE:
+            if (a.K == 1024) return launch_mt<1, 8, 4, EPI_STORE>(a, a.N / 16, st);
+            return launch_mt<1, 16, 8, EPI_STORE>(a, a.N / 16, st);
+        case EPI_RESID:
+            if (a.K == 1024) return launch_mt<1, 8, 4, EPI_RESID>(a, a.N / 16, st);
+            return launch_mt<1, 16, 8, EPI_RESID>(a, a.N / 16, st);
+        case EPI_SILU:
+            T3_REQUIRE(a.K == 1024 && a.N % 64 == 0, "gemm_silu: K must be 1024, N = 2F with F % 32 == 0");
+            return launch_mt<2, 8, 4, EPI_SILU>(a, a.N / 32, st);
+        case EPI_QKV_ROPE:
+            T3_REQUIRE(a.K == 1024 && a.kv.hd == 64 && a.N == 3 * a.kv.H * 64, "gemm_qkv: needs K=1024, head_dim 64");
+            T3_REQUIRE(a.ldc % 4 == 0, "gemm_qkv: ldc must be a multiple of 4");
+            return launch_mt<2, 8, 4, EPI_QKV_ROPE>(a, a.N / 32, st);
+    }
+    t3_set_error("gemm: unknown epilogue");
+    return 1;
+}

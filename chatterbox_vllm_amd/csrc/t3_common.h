@@ -1,0 +1,106 @@
+// Shared device helpers and the internal launcher interface of the T3 engine (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+typedef unsigned short bf16_t;   // storage type: raw bf16 bits
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define T3_PAGE 64               // tokens per KV page
+#define T3_WAVE 64
+
+__device__ __forceinline__ float bf2f(bf16_t x) { return __uint_as_float(((unsigned)x) << 16); }
+// round-to-nearest-even, NaN stays NaN (v_cvt_pk_bf16_f32)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }   // round through bf16
+__device__ __forceinline__ float bf_lo(unsigned w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+__device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
+    return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+}
+
+// ---- error plumbing (host) -------------------------------------------------------
+void t3_set_error(const std::string& msg);
+#define T3_HIP_CHECK(expr)                                                                   \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) {                                                              \
+            t3_set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                 \
+            return 1;                                                                        \
+        }                                                                                    \
+    } while (0)
+#define T3_REQUIRE(cond, msg)                                                                \
+    do {                                                                                     \
+        if (!(cond)) { t3_set_error(std::string(msg) + " [" #cond "]"); return 1; }          \
+    } while (0)
+
+// ---- KV cache geometry -------------------------------------------------------------
+// pool[layer][page][kv(0=K,1=V)][head][token(64)][head_dim]   bf16
+// layer_stride = n_pages * 2 * H * 64 * hd elements.
+struct KvView {
+    bf16_t* pool;
+    int64_t layer_stride;        // elements
+    const int32_t* block_table;  // [n_streams][max_pages]
+    int32_t max_pages;
+    int32_t H, hd;
+};
+
+// ---- launchers (all asynchronous on `st`) -------------------------------------------
+enum GemmEpilogue { EPI_STORE = 0, EPI_RESID = 1, EPI_SILU = 2, EPI_QKV_ROPE = 3 };
+
+struct GemmArgs {
+    const bf16_t* A; int lda;          // activations [M, K]
+    const int32_t* a_rows;             // optional gather of A rows (nullptr = identity)
+    const bf16_t* Wt;                  // weights in tile order
+    bf16_t* C; int ldc;                // output
+    int M, N, K;
+    int n_valid;                       // columns >= n_valid are not stored (EPI_STORE)
+    // EPI_QKV_ROPE
+    const bf16_t* rope; const int32_t* pos; const int32_t* row_stream;
+    KvView kv; int layer;
+};
+int launch_gemm(int epi, const GemmArgs& a, hipStream_t st);
+int launch_repack(const bf16_t* w, bf16_t* wt, int N, int K, hipStream_t st);
+int launch_add_rmsnorm(const bf16_t* x, bf16_t* res, const bf16_t* w, bf16_t* xn, int rows, int d,
+                       float eps, hipStream_t st);
+int launch_attn_decode(const bf16_t* qkv, int ldq, bf16_t* out, int rows, const int32_t* row_stream,
+                       const int32_t* row_ctx, const KvView& kv, int layer, hipStream_t st);
+// tiles_dev: (sequence index, first query row) per 64-row query tile
+int launch_attn_prefill(const bf16_t* qkv, int ldq, bf16_t* out, const int32_t* seq_start_dev,
+                        const int32_t* tiles_dev, int ntiles, int H, int hd, hipStream_t st);
+
+struct EmbedArgs {
+    bf16_t* out; int d;                 // [rows, d]
+    int rows;
+    const int32_t* kind;                // per row: 0 cond row, 1 text, 2 zero, 3 SOS, 4 decode token
+    const int32_t* idx;                 // cond row / text id / - / - / slot
+    const int32_t* aux;                 // cond buffer index / text position / - / - / -
+    const float* cond;                  // [n_cond_bufs, 34, d] fp32
+    const bf16_t* text_emb; const bf16_t* text_pos; const bf16_t* speech_emb; const bf16_t* speech_pos;
+    const int32_t* last_token;          // [slots] un-offset speech id per slot
+    int sos_id;
+};
+int launch_embed(const EmbedArgs& a, hipStream_t st);
+
+struct SampleArgs {
+    const bf16_t* logits; int ldl; int vocab;      // speech logits rows
+    const int32_t* row_c; const int32_t* row_u;    // per request rows (row_u < 0: single stream)
+    const int32_t* slot;                           // per request slot (seen / last_token index), nullptr = i
+    int n; float cfg_scale;
+    const float* rep_penalty;                      // per request
+    const float* temperature; const float* top_p; const float* min_p;   // per request (nullptr = greedy)
+    const uint64_t* seed; const int32_t* step;     // per request RNG key / counter
+    uint8_t* seen; int seen_stride;                // [slots, seen_stride] column space (offset 1000)
+    int32_t* last_token;                           // [slots] written with the un-offset id (may be null)
+    int32_t* out_tokens;                           // [n] +1000 space
+    float* out_logits;                             // optional [slots, vocab+1000] penalised fp32 logits
+};
+int launch_sample(const SampleArgs& a, hipStream_t st);
+int launch_seen_init(uint8_t* seen_row, int seen_stride, const int32_t* ids_dev, int n_ids, hipStream_t st);

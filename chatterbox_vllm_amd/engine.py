@@ -1,0 +1,235 @@
+"""``T3Engine``: the object ``ChatterboxTTS`` holds where the reference holds ``vllm.LLM``.
+
+It accepts the same call the reference makes
+(src/chatterbox_vllm/tts.py:365-370, 408-418)::
+
+    outs = engine.generate(
+        [{"prompt": "[START]Hello.[STOP]", "multi_modal_data": {"conditionals": [cond_emb]}}, ...],
+        sampling_params=SamplingParams(temperature=..., stop_token_ids=[7562], max_tokens=..., top_p=...,
+                                       repetition_penalty=..., min_p=..., seed=...))
+    outs[i].outputs[0].token_ids      # ids in the +1000 space, stop id included
+
+and returns results in input order.  All arithmetic runs in ``libt3hip.so`` (HIP kernels for
+gfx950 behind a C ABI); this module only tokenises, queues and collects.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass, field
+from typing import Callable, Dict, Iterable, List, Optional, Sequence, Union
+
+import torch
+
+from . import _capi
+from .config import (T3ModelConfig, CONDITIONING_SIZE, SPEECH_TOKEN_OFFSET, STOP_SPEECH_TOKEN)
+from .weights import rope_table, route_checkpoint
+
+
+@dataclass
+class SamplingParams:
+    """The fields of ``vllm.SamplingParams`` the T3 path uses, with vLLM's defaults."""
+    temperature: float = 1.0
+    top_p: float = 1.0
+    min_p: float = 0.0
+    repetition_penalty: float = 1.0
+    max_tokens: int = 16
+    stop_token_ids: Optional[Sequence[int]] = None
+    seed: Optional[int] = None
+
+    def __post_init__(self):
+        if self.temperature < 0:
+            raise ValueError("temperature must be non-negative")
+        if not 0 < self.top_p <= 1:
+            raise ValueError("top_p must be in (0, 1]")
+        if not 0 <= self.min_p <= 1:
+            raise ValueError("min_p must be in [0, 1]")
+        if self.repetition_penalty <= 0:
+            raise ValueError("repetition_penalty must be positive")
+        if self.max_tokens < 1:
+            raise ValueError("max_tokens must be at least 1")
+
+
+@dataclass
+class CompletionOutput:
+    index: int
+    token_ids: List[int]
+    finish_reason: Optional[str] = None      # "stop" | "length"
+
+
+@dataclass
+class RequestOutput:
+    request_id: str
+    prompt: Optional[str]
+    prompt_token_ids: List[int]
+    outputs: List[CompletionOutput] = field(default_factory=list)
+    finished: bool = True
+
+
+_FINISH = {1: "stop", 2: "length"}
+
+
+class T3Engine:
+    """One engine per GPU.  Not re-entrant: ``generate`` calls must not overlap (the
+    reference's ``LLM.generate`` has the same contract)."""
+
+    def __init__(self, model_config: T3ModelConfig, state_dict: Dict[str, torch.Tensor],
+                 tokenizer: Optional[Callable[..., List[int]]] = None, *,
+                 max_model_len: int = 1000, max_num_seqs: int = 32, cfg_scale: Optional[float] = None,
+                 cfg_paired: Optional[bool] = None, device: int = 0, enforce_eager: bool = False,
+                 kv_pages: int = 0, max_prefill_rows: int = 2048, **_ignored_vllm_kwargs):
+        if cfg_scale is None:                      # models/t3/t3.py:343
+            cfg_scale = float(os.environ.get("CHATTERBOX_CFG_SCALE", "0.5"))
+        if cfg_paired is None:
+            cfg_paired = True                      # the reference always runs both halves
+        self.model_config = model_config
+        self.tokenizer = tokenizer
+        self.max_model_len = int(max_model_len)
+        self.max_num_seqs = int(max_num_seqs)
+        self.cfg_scale = float(cfg_scale)
+        self.cfg_paired = bool(cfg_paired)
+        self.device = int(device)
+        self._lib = _capi.load()
+        m = model_config
+        cfg = _capi.T3Config(
+            n_layers=m.n_layers, d_model=m.d_model, n_heads=m.n_heads, head_dim=m.head_dim, d_ff=m.d_ff,
+            text_vocab=m.text_vocab, speech_vocab=m.speech_vocab, text_pos_rows=m.text_pos_rows,
+            speech_pos_rows=m.speech_pos_rows, max_model_len=self.max_model_len, max_num_seqs=self.max_num_seqs,
+            cfg_paired=int(self.cfg_paired), max_prefill_rows=int(max_prefill_rows), device=self.device,
+            use_graphs=int(not enforce_eager), reserved0=0, cfg_scale=self.cfg_scale, rms_eps=m.rms_eps,
+            kv_pages=int(kv_pages))
+        self._h = C.c_void_p()
+        _capi.check(self._lib, self._lib.t3_engine_create(C.byref(cfg), C.byref(self._h)))
+        self._next_id = 0
+        self._load(state_dict)
+
+    # ---- weights -----------------------------------------------------------------
+    def _load_tensor(self, name: str, t: torch.Tensor) -> None:
+        t = t.detach().to(device="cpu", dtype=torch.bfloat16).contiguous()
+        shape = (C.c_int64 * t.dim())(*t.shape)
+        _capi.check(self._lib, self._lib.t3_engine_load_tensor(self._h, name.encode(), _capi.ptr(t), shape, t.dim(), 0))
+
+    def _load(self, state_dict: Dict[str, torch.Tensor]) -> None:
+        keep, self.skipped_tensors = route_checkpoint(state_dict.items(), self.model_config)
+        for name, t in keep.items():
+            self._load_tensor(name, t)
+        self._load_tensor("rope.cos_sin", rope_table(self.model_config, self.max_model_len))
+        _capi.check(self._lib, self._lib.t3_engine_finalize(self._h))
+
+    # ---- request level -------------------------------------------------------------
+    def add_request(self, text_ids: Sequence[int], cond_emb: torch.Tensor, sp: SamplingParams,
+                    request_id: Optional[int] = None) -> int:
+        assert cond_emb is not None, "Conditionals are required for prefill"            # t3.py:248
+        assert cond_emb.shape[0] == CONDITIONING_SIZE, "Conditionals must be CONDITIONING_SIZE tokens long"  # t3.py:250
+        assert cond_emb.shape[1] == self.model_config.d_model
+        rid = self._next_id if request_id is None else int(request_id)
+        self._next_id = max(self._next_id, rid) + 1
+        ids = (C.c_int32 * len(text_ids))(*[int(t) for t in text_ids])
+        cond = cond_emb.detach().to(device="cpu", dtype=torch.float32).contiguous()
+        stop = list(sp.stop_token_ids or [])
+        if len(stop) > 1:
+            raise ValueError("the T3 engine supports a single stop token id")
+        s = _capi.T3Sampling(temperature=sp.temperature, top_p=sp.top_p, min_p=sp.min_p,
+                             repetition_penalty=sp.repetition_penalty, max_tokens=int(sp.max_tokens),
+                             stop_token=int(stop[0]) if stop else -1, has_seed=int(sp.seed is not None), reserved0=0,
+                             seed=int(sp.seed or 0) & (2 ** 64 - 1))
+        _capi.check(self._lib, self._lib.t3_engine_add_request(
+            self._h, rid, ids, len(text_ids), C.cast(_capi.ptr(cond), C.POINTER(C.c_float)), C.byref(s)))
+        return rid
+
+    def step(self):
+        """One scheduler iteration -> list of (request_id, token_id, finish_reason | None)."""
+        cap = self.max_num_seqs
+        rid = (C.c_int64 * cap)()
+        tok = (C.c_int32 * cap)()
+        fin = (C.c_int32 * cap)()
+        n = C.c_int32(0)
+        _capi.check(self._lib, self._lib.t3_engine_step(self._h, rid, tok, fin, cap, C.byref(n)))
+        return [(rid[i], tok[i], _FINISH.get(fin[i])) for i in range(n.value)]
+
+    def has_unfinished(self) -> bool:
+        return bool(self._lib.t3_engine_has_unfinished(self._h))
+
+    def abort(self, request_id: int) -> None:
+        _capi.check(self._lib, self._lib.t3_engine_abort(self._h, int(request_id)))
+
+    def stats(self) -> _capi.T3StepStats:
+        s = _capi.T3StepStats()
+        _capi.check(self._lib, self._lib.t3_engine_get_stats(self._h, C.byref(s)))
+        return s
+
+    def set_timing(self, on: bool) -> None:
+        _capi.check(self._lib, self._lib.t3_engine_set_timing(self._h, int(on)))
+
+    def set_keep_logits(self, on: bool) -> None:
+        _capi.check(self._lib, self._lib.t3_engine_set_keep_logits(self._h, int(on)))
+
+    def last_logits(self, request_id: int) -> torch.Tensor:
+        out = torch.empty(self.model_config.speech_vocab + SPEECH_TOKEN_OFFSET, dtype=torch.float32)
+        _capi.check(self._lib, self._lib.t3_engine_last_logits(
+            self._h, int(request_id), C.cast(_capi.ptr(out), C.POINTER(C.c_float))))
+        return out
+
+    # ---- the LLM.generate stand-in ---------------------------------------------------
+    def _tokenize(self, item: dict) -> List[int]:
+        if "prompt_token_ids" in item:
+            return [int(t) for t in item["prompt_token_ids"]]
+        if self.tokenizer is None:
+            raise ValueError("engine has no tokenizer: pass prompt_token_ids")
+        kw = item.get("tokenization_kwargs") or {}
+        return list(self.tokenizer(item["prompt"], **kw))
+
+    def generate(self, request_items: Union[dict, Sequence[dict]],
+                 sampling_params: Union[SamplingParams, Sequence[SamplingParams], None] = None,
+                 on_step: Optional[Callable[["T3Engine"], None]] = None) -> List[RequestOutput]:
+        if isinstance(request_items, dict):
+            request_items = [request_items]
+        n = len(request_items)
+        if sampling_params is None:
+            sampling_params = SamplingParams()
+        sps = list(sampling_params) if isinstance(sampling_params, (list, tuple)) else [sampling_params] * n
+        if len(sps) != n:
+            raise ValueError("one SamplingParams per request item is required")
+        outs: List[RequestOutput] = []
+        by_id: Dict[int, RequestOutput] = {}
+        added: List[int] = []
+        try:
+            for i, (item, sp) in enumerate(zip(request_items, sps)):
+                ids = self._tokenize(item)
+                conds = (item.get("multi_modal_data") or {}).get("conditionals")
+                assert conds is not None and len(conds) > 0, "Conditionals are required for prefill"   # t3.py:248
+                assert len(conds) == 1, "Only one conditional embedding is supported for prefill"       # t3.py:249
+                rid = self.add_request(ids, conds[0], sp)
+                added.append(rid)
+                ro = RequestOutput(request_id=str(rid), prompt=item.get("prompt"), prompt_token_ids=ids,
+                                   outputs=[CompletionOutput(index=0, token_ids=[])], finished=False)
+                outs.append(ro)
+                by_id[rid] = ro
+        except Exception:
+            for rid in added:
+                self.abort(rid)
+            raise
+        while self.has_unfinished():
+            for rid, tok, fin in self.step():
+                ro = by_id.get(rid)
+                if ro is None:
+                    continue
+                ro.outputs[0].token_ids.append(tok)
+                if fin is not None:
+                    ro.outputs[0].finish_reason = fin
+                    ro.finished = True
+            if on_step is not None:
+                on_step(self)
+        return outs
+
+    # ---- life cycle -------------------------------------------------------------------
+    def shutdown(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.t3_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.shutdown()
+        except Exception:
+            pass

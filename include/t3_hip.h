@@ -1,0 +1,154 @@
+/*
+ * t3_hip.h -- C ABI of the MI355X (gfx950) T3 speech-token decode engine.
+ *
+ * Everything the Python host layer (or any other FFI: cgo, JNI, ctypes) needs is
+ * declared here: plain pointers and sizes, int status codes, no C++ or torch types.
+ * Status 0 = success; on failure t3_last_error() returns a message for the calling
+ * thread.  Pointers named *_dev are device (HIP) addresses, everything else is host
+ * memory.  All device work of a call is enqueued on the engine's own HIP stream (or
+ * on the `stream` argument for the per-op entry points; 0 = the default stream).
+ *
+ * The reference has no native code of its own: the arithmetic of this path runs
+ * inside the third-party vLLM wheel.  Each entry point therefore cites the Python
+ * interface of the reference (paths relative to the reference tree) whose job it
+ * takes over.
+ */
+#ifndef T3_HIP_H
+#define T3_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define T3_ABI_VERSION 1
+
+typedef struct t3_engine t3_engine;
+
+/* Engine construction parameters.
+ * Replaces the keyword arguments of vllm.LLM(...) built at
+ * src/chatterbox_vllm/tts.py:130-140 plus the model constants of
+ * t3-model/config.json:8-32 and models/t3/modules/t3_config.py:2-21. */
+typedef struct t3_config {
+    int32_t n_layers, d_model, n_heads, head_dim, d_ff;
+    int32_t text_vocab, speech_vocab, text_pos_rows, speech_pos_rows;
+    int32_t max_model_len;     /* prompt + generated positions per request            */
+    int32_t max_num_seqs;      /* requests decoded concurrently                       */
+    int32_t cfg_paired;        /* 1: each request runs a cond and an uncond KV stream */
+    int32_t max_prefill_rows;  /* prompt rows (per stream) admitted in one step       */
+    int32_t device;            /* HIP device ordinal                                  */
+    int32_t use_graphs;        /* 1: replay decode steps from captured HIP graphs     */
+    int32_t reserved0;
+    float cfg_scale;           /* CHATTERBOX_CFG_SCALE, models/t3/t3.py:343           */
+    float rms_eps;
+    int64_t kv_pages;          /* KV pool size in 64-token pages; 0 = no oversubscription */
+} t3_config;
+
+/* Per-request sampling parameters: the vllm.SamplingParams fields set at
+ * src/chatterbox_vllm/tts.py:410-417. */
+typedef struct t3_sampling {
+    float temperature, top_p, min_p, repetition_penalty;
+    int32_t max_tokens;
+    int32_t stop_token;        /* in the engine's +1000 id space (7562)               */
+    int32_t has_seed;
+    int32_t reserved0;
+    uint64_t seed;
+} t3_sampling;
+
+/* Counters of the last t3_engine_step (for benchmarks / tracing). */
+typedef struct t3_step_stats {
+    int32_t prefill_requests, prefill_rows, decode_requests, decode_rows;
+    int64_t decode_ctx_tokens; /* sum over decode streams of context length           */
+    int32_t free_pages, waiting, running, reserved0;
+    float decode_gpu_ms;       /* HIP-event time of the decode part, 0 if not timed   */
+    float prefill_gpu_ms;
+} t3_step_stats;
+
+const char* t3_last_error(void);
+int t3_abi_version(void);
+
+/* ---- engine life cycle: stands in for vllm.LLM.__init__ (tts.py:140) and
+ *      T3VllmModel.__init__/load_weights (models/t3/t3.py:305-379) ---------------- */
+int t3_engine_create(const t3_config* cfg, t3_engine** out);
+/* `name` is the checkpoint tensor name routed by t3.py:347-369 (tfmr.*, text_emb.weight,
+ * speech_emb.weight, text_pos_emb.emb.weight, speech_pos_emb.emb.weight,
+ * speech_head.weight) or "rope.cos_sin" ([max_pos, head_dim] bf16, cos|sin).
+ * `data` is host memory holding bf16 (dtype 0) in row-major `shape`. */
+int t3_engine_load_tensor(t3_engine* e, const char* name, const void* data,
+                          const int64_t* shape, int32_t ndim, int32_t dtype);
+/* Repack the loaded matrices into the streaming tile order; must follow the last load. */
+int t3_engine_finalize(t3_engine* e);
+int t3_engine_destroy(t3_engine* e);
+
+/* ---- request flow: stands in for LLM.generate(request_items, SamplingParams)
+ *      (tts.py:365-370, 408-418) and the per-request prompt layout of
+ *      T3MultiModalProcessor.apply (t3.py:229-262) --------------------------------- */
+/* text_ids: tokenizer output for "[START]...[STOP]"; cond: fp32 [34, d_model] (host). */
+int t3_engine_add_request(t3_engine* e, int64_t req_id, const int32_t* text_ids, int32_t n_text,
+                          const float* cond, const t3_sampling* sp);
+/* One scheduler iteration: admit + prefill new requests, decode one token for every
+ * running request.  out_* have room for `cap` entries; *n_out receives the number of
+ * (req_id, token, finished) triples produced.  finished: 0 running, 1 stop token,
+ * 2 length.  Tokens are in the +1000 id space, the stop token is reported. */
+int t3_engine_step(t3_engine* e, int64_t* out_req_ids, int32_t* out_tokens, int32_t* out_finished,
+                   int32_t cap, int32_t* n_out);
+int t3_engine_abort(t3_engine* e, int64_t req_id);
+int t3_engine_has_unfinished(t3_engine* e);
+int t3_engine_get_stats(t3_engine* e, t3_step_stats* out);
+/* Enable HIP-event timing of the prefill / decode parts of each step (adds a sync). */
+int t3_engine_set_timing(t3_engine* e, int32_t on);
+
+/* ---- debugging taps for parity tests ------------------------------------------- */
+/* Keep the CFG-combined, penalised fp32 logits of every sampled token (turns graph replay
+ * off).  The logits are what models/t3/t3.py:725-739 returns, after the sampler's
+ * repetition penalty. */
+int t3_engine_set_keep_logits(t3_engine* e, int32_t on);
+/* Copies the logits [speech_vocab + 1000] that produced the most recent token of the
+ * still-running request `req_id` into host memory `out`. */
+int t3_engine_last_logits(t3_engine* e, int64_t req_id, float* out);
+
+/* ---- per-op entry points (parity tests call the kernels one by one).
+ *      All tensors are device memory, bf16 unless noted, row-major. ---------------- */
+
+/* Repack W[N,K] (bf16, N%16==0, K%32==0) into the streaming tile order used by t3_op_gemm. */
+int t3_op_repack_weight(const void* w_dev, void* wt_dev, int32_t N, int32_t K, void* stream);
+/* res = bf16(x + res) when x_dev != NULL (else res is used as is); xn = rmsnorm(res) * w.
+ * Equivalent of vLLM's fused_add_rms_norm reached from LlamaDecoderLayer (t3.py:768-773). */
+int t3_op_add_rmsnorm(const void* x_dev, void* res_dev, const void* w_dev, void* xn_dev,
+                      int32_t rows, int32_t d, float eps, void* stream);
+/* out[M,N] = bf16(A[M,K] @ W[N,K]^T), W given in tile order.  epilogue 0: store;
+ * 1: out = bf16(bf16(acc) + out) (residual add in place). */
+int t3_op_gemm(const void* a_dev, const void* wt_dev, void* out_dev, int32_t M, int32_t N, int32_t K,
+               int32_t ldc, int32_t epilogue, void* stream);
+/* h[M,F] = bf16(bf16(silu(g)) * u) with [g|u] = bf16(A[M,K] @ Wgu[2F,K]^T)  (LlamaMLP). */
+int t3_op_gemm_silu(const void* a_dev, const void* wt_dev, void* h_dev, int32_t M, int32_t F, int32_t K,
+                    void* stream);
+/* qkv[M,3*H*hd] = A @ Wqkv^T, q and k rotated (half-split RoPE, table rope_dev [max_pos, hd]
+ * cos|sin) at positions pos_dev[M]; k and v rows are also written into the paged KV cache of
+ * layer `layer` through stream_dev[M] (KV stream of each row, <0 = skip) and the block table. */
+int t3_op_gemm_qkv_rope(const void* a_dev, const void* wt_dev, void* qkv_dev, int32_t M, int32_t H, int32_t hd,
+                        int32_t K, const void* rope_dev, const int32_t* pos_dev, const int32_t* stream_dev,
+                        void* kv_pool_dev, int64_t layer_stride_elems, int32_t layer,
+                        const int32_t* block_table_dev, int32_t max_pages, void* stream);
+/* Single-query attention over the paged KV cache: row r attends to positions
+ * [0, ctx_dev[r]) of KV stream stream_dev[r]; q is read from qkv_dev[r, 0:H*hd]. */
+int t3_op_attn_decode(const void* qkv_dev, void* out_dev, int32_t rows, int32_t H, int32_t hd,
+                      const int32_t* stream_dev, const int32_t* ctx_dev, const void* kv_pool_dev,
+                      int64_t layer_stride_elems, int32_t layer, const int32_t* block_table_dev,
+                      int32_t max_pages, void* stream);
+/* Causal attention inside packed prompt rows: sequence i owns rows [seq_start[i], seq_start[i+1]). */
+int t3_op_attn_prefill(const void* qkv_dev, void* out_dev, int32_t n_seqs, const int32_t* seq_start_dev,
+                       const int32_t* seq_start_host, int32_t H, int32_t hd, void* stream);
+/* logits rows (bf16 [*, ldl]) -> CFG combine, +1000 offset, repetition penalty over seen_dev
+ * ([n, seen_stride] bytes, column space), greedy argmax (lowest index wins ties).
+ * row_c/row_u: logits row of the cond / uncond stream per request (row_u < 0: no CFG). */
+int t3_op_sample_greedy(const void* logits_dev, int32_t ldl, int32_t vocab, const int32_t* row_c_dev,
+                        const int32_t* row_u_dev, int32_t n, float cfg_scale, const float* rep_penalty_dev,
+                        uint8_t* seen_dev, int32_t seen_stride, int32_t* out_tokens_dev,
+                        float* out_logits_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* T3_HIP_H */

@@ -1,0 +1,281 @@
+"""Per-kernel parity on the GPU, driven through the C ABI (t3_op_* of include/t3_hip.h).
+
+Each kernel is checked against a plain fp32 PyTorch restatement of the same arithmetic
+contract the CPU oracle uses (oracle/t3_oracle.py header).  bf16 outputs may differ from
+the checker only where the fp32 summation order flips a rounding: at most 1 bf16 ulp on
+at most 2 % of the elements; integer results (token ids, cache placement) are exact.
+"""
+import ctypes as C
+
+import pytest
+import torch
+
+from chatterbox_vllm_amd.config import T3ModelConfig
+from chatterbox_vllm_amd import weights as W
+from _util import assert_bf16_close, call, p, repack, r16, ulp_distance
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("M", [1, 7, 16, 33, 64, 100, 128, 300])
+@pytest.mark.parametrize("N,K", [(1024, 1024), (1024, 4096), (8208, 1024)])
+def test_gemm_store_and_residual(capi, M, N, K):
+    a = _rand((M, K), 1).to(DEV)
+    w = _rand((N, K), 2, 0.02).to(DEV)
+    wt = repack(capi, w)
+    out = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    call(capi, "t3_op_gemm", p(a), p(wt), p(out), M, N, K, N, 0, None)
+    torch.cuda.synchronize()
+    ref = a.float() @ w.float().T
+    assert_bf16_close(out, ref, what=f"gemm M={M} N={N} K={K}")
+    if N == 1024:
+        res = _rand((M, N), 3).to(DEV)
+        res0 = res.clone()
+        call(capi, "t3_op_gemm", p(a), p(wt), p(res), M, N, K, N, 1, None)
+        torch.cuda.synchronize()
+        assert_bf16_close(res, r16(ref) + res0.float(), what="gemm+residual")
+
+
+def test_gemm_partial_columns_are_not_written(capi):
+    M, N, K, ldc = 5, 8208, 1024, 8194          # speech head: 8194 real columns in a 16-padded matrix
+    a = _rand((M, K), 4).to(DEV)
+    w = _rand((N, K), 5, 0.02).to(DEV)
+    wt = repack(capi, w)
+    out = torch.full((M * ldc + 64,), 7.0, dtype=torch.bfloat16, device=DEV)
+    call(capi, "t3_op_gemm", p(a), p(wt), p(out), M, N, K, ldc, 0, None)
+    torch.cuda.synchronize()
+    ref = (a.float() @ w.float().T)[:, :ldc]
+    assert_bf16_close(out[: M * ldc].view(M, ldc), ref, what="gemm ldc<N")
+    assert (out[M * ldc:] == 7.0).all()
+
+
+def test_gemm_rows_do_not_depend_on_batch(capi):
+    """Batch invariance: a row's result is bit-identical whatever else is in the launch."""
+    K, N = 1024, 1024
+    a = _rand((128, K), 6).to(DEV)
+    w = _rand((N, K), 7, 0.02).to(DEV)
+    wt = repack(capi, w)
+    full = torch.zeros(128, N, dtype=torch.bfloat16, device=DEV)
+    call(capi, "t3_op_gemm", p(a), p(wt), p(full), 128, N, K, N, 0, None)
+    for M in (1, 3, 16, 40, 64):
+        part = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+        call(capi, "t3_op_gemm", p(a), p(wt), p(part), M, N, K, N, 0, None)
+        torch.cuda.synchronize()
+        assert torch.equal(part, full[:M]), f"rows change with M={M}"
+
+
+@pytest.mark.parametrize("M", [1, 20, 64, 130])
+def test_gemm_silu(capi, M):
+    K, F = 1024, 4096
+    a = _rand((M, K), 8).to(DEV)
+    w = _rand((2 * F, K), 9, 0.05).to(DEV)
+    wt = repack(capi, w)
+    h = torch.zeros(M, F, dtype=torch.bfloat16, device=DEV)
+    call(capi, "t3_op_gemm_silu", p(a), p(wt), p(h), M, F, K, None)
+    torch.cuda.synchronize()
+    gu = r16(a.float() @ w.float().T)
+    g, u = gu[:, :F], gu[:, F:]
+    ref = r16(g / (1 + torch.exp(-g))) * u
+    # a flipped rounding of g or u moves the product by up to 2 ulp
+    assert_bf16_close(h, ref, max_ulp=2, max_frac=0.03, what="gemm_silu")
+
+
+def _kv_setup(n_streams, max_pages, n_layers, H=16, hd=64, seed=0):
+    n_pages = n_streams * max_pages
+    page_elems = 2 * H * 64 * hd
+    pool = torch.zeros(n_layers * n_pages * page_elems, dtype=torch.bfloat16, device=DEV)
+    g = torch.Generator().manual_seed(seed)
+    bt = torch.randperm(n_pages, generator=g).to(torch.int32).view(n_streams, max_pages).contiguous()
+    return pool, bt, n_pages * page_elems
+
+
+def _cache_rows(pool, layer_stride, layer, bt, stream, npos, kv, H=16, hd=64):
+    """[npos, H, hd] view of what the cache holds for one stream."""
+    v = pool[layer * layer_stride:(layer + 1) * layer_stride].view(-1, 2, H, 64, hd)
+    rows = []
+    for pos in range(npos):
+        rows.append(v[int(bt[stream, pos // 64]), kv, :, pos % 64, :])
+    return torch.stack(rows)
+
+
+@pytest.mark.parametrize("M", [1, 19, 64, 150])
+def test_gemm_qkv_rope_and_cache_write(capi, M):
+    cfg = T3ModelConfig.english()
+    H, hd, K = 16, 64, 1024
+    a = _rand((M, K), 10).to(DEV)
+    w = _rand((3 * H * hd, K), 11, 0.03).to(DEV)
+    wt = repack(capi, w)
+    rope = W.rope_table(cfg, 1000).to(DEV)
+    g = torch.Generator().manual_seed(12)
+    n_streams, max_pages = 4, 16
+    pool, bt, layer_stride = _kv_setup(n_streams, max_pages, 2)
+    # rows spread over streams with distinct positions per stream
+    stream = (torch.arange(M) % n_streams).to(torch.int32)
+    pos = torch.zeros(M, dtype=torch.int32)
+    perm = {s: torch.randperm(1000, generator=g) for s in range(n_streams)}
+    for r in range(M):
+        s = int(stream[r]); pos[r] = perm[s][r // n_streams]
+    if M > 2:
+        stream[2] = -1                                   # a row that must not touch the cache
+    qkv = torch.zeros(M, 3 * H * hd, dtype=torch.bfloat16, device=DEV)
+    btd, posd, std = bt.to(DEV), pos.to(DEV), stream.to(DEV)
+    call(capi, "t3_op_gemm_qkv_rope", p(a), p(wt), p(qkv), M, H, hd, K, p(rope), p(posd), p(std), p(pool),
+         layer_stride, 1, p(btd), max_pages, None)
+    torch.cuda.synchronize()
+    ref = r16(a.float() @ w.float().T).cpu()
+    cs = rope.float().cpu()[pos.long()]
+    cos, sin = cs[:, None, :32], cs[:, None, 32:]
+
+    def rot(t):
+        t = t.view(M, H, hd)
+        x, y = t[..., :32], t[..., 32:]
+        return torch.cat([x * cos - y * sin, y * cos + x * sin], -1).reshape(M, H * hd)
+    refq, refk, refv = rot(ref[:, :1024]), rot(ref[:, 1024:2048]), ref[:, 2048:]
+    got = qkv.cpu()
+    assert_bf16_close(got[:, :1024], refq, max_ulp=2, max_frac=0.03, what="q")
+    assert_bf16_close(got[:, 1024:2048], refk, max_ulp=2, max_frac=0.03, what="k")
+    assert_bf16_close(got[:, 2048:], refv, what="v")
+    # the cache holds exactly the rows just written, at (block_table[stream, pos/64], pos%64); layer 0 untouched
+    poolc = pool.cpu()
+    v = poolc[layer_stride:2 * layer_stride].view(-1, 2, H, 64, hd)
+    for r in range(M):
+        s = int(stream[r])
+        if s < 0:
+            continue
+        pg = int(bt[s, int(pos[r]) // 64])
+        assert torch.equal(v[pg, 0, :, int(pos[r]) % 64, :].reshape(-1), got[r, 1024:2048])
+        assert torch.equal(v[pg, 1, :, int(pos[r]) % 64, :].reshape(-1), got[r, 2048:])
+    written = sum(1 for r in range(M) if int(stream[r]) >= 0)
+    assert int((v != 0).any(-1).any(2).any(1).sum()) <= written         # no other (page, token) slot was touched
+    assert not poolc[:layer_stride].any()
+
+
+@pytest.mark.parametrize("rows,d", [(1, 1024), (37, 1024), (5, 4096)])
+def test_add_rmsnorm(capi, rows, d):
+    x = _rand((rows, d), 13).to(DEV)
+    res = _rand((rows, d), 14).to(DEV)
+    w = (1 + 0.1 * _rand((d,), 15).float()).to(torch.bfloat16).to(DEV)
+    xn = torch.zeros(rows, d, dtype=torch.bfloat16, device=DEV)
+    res_in = res.clone()
+    call(capi, "t3_op_add_rmsnorm", p(x), p(res), p(w), p(xn), rows, d, C.c_float(1e-5), None)
+    torch.cuda.synchronize()
+    z = r16(x.float() + res_in.float())
+    assert torch.equal(res.float(), z)                                     # residual add is exact
+    ref = r16(z * torch.rsqrt((z * z).mean(-1, keepdim=True) + 1e-5)) * w.float()
+    assert_bf16_close(xn, ref, what="rmsnorm")
+    # without x the residual is left alone
+    res2 = res_in.clone()
+    call(capi, "t3_op_add_rmsnorm", None, p(res2), p(w), p(xn), rows, d, C.c_float(1e-5), None)
+    torch.cuda.synchronize()
+    assert torch.equal(res2, res_in)
+    zz = res_in.float()
+    assert_bf16_close(xn, r16(zz * torch.rsqrt((zz * zz).mean(-1, keepdim=True) + 1e-5)) * w.float(), what="rmsnorm(no add)")
+
+
+def _fill_cache(pool, layer_stride, layer, bt, stream, k, v, H=16, hd=64):
+    view = pool[layer * layer_stride:(layer + 1) * layer_stride].view(-1, 2, H, 64, hd)
+    for pos in range(k.shape[0]):
+        pg = int(bt[stream, pos // 64])
+        view[pg, 0, :, pos % 64, :] = k[pos]
+        view[pg, 1, :, pos % 64, :] = v[pos]
+
+
+def test_attn_decode_matches_softmax_attention(capi):
+    H, hd = 16, 64
+    ctxs = [1, 2, 63, 64, 65, 200, 511, 513, 1000]
+    n = len(ctxs)
+    pool, bt, layer_stride = _kv_setup(n, 16, 1, seed=3)
+    pool.copy_(_rand(tuple(pool.shape), 20, 3.0))            # stale finite data in every page
+    ks, vs = [], []
+    for s, c in enumerate(ctxs):
+        k, v = _rand((c, H, hd), 30 + s).to(DEV), _rand((c, H, hd), 60 + s).to(DEV)
+        _fill_cache(pool, layer_stride, 0, bt, s, k, v)
+        ks.append(k.float()), vs.append(v.float())
+    qkv = torch.zeros(n, 3 * H * hd, dtype=torch.bfloat16, device=DEV)
+    q = _rand((n, H, hd), 21).to(DEV)
+    qkv[:, : H * hd] = q.view(n, -1)
+    out = torch.zeros(n, H * hd, dtype=torch.bfloat16, device=DEV)
+    order = torch.tensor([3, 0, 8, 1, 2, 7, 4, 6, 5], dtype=torch.int32)     # rows need not be stream-ordered
+    qkv_o = qkv[order.long()].contiguous()
+    ctx_t = torch.tensor([ctxs[i] for i in order.tolist()], dtype=torch.int32, device=DEV)
+    call(capi, "t3_op_attn_decode", p(qkv_o), p(out), n, H, hd, p(order.to(DEV)), p(ctx_t), p(pool), layer_stride, 0,
+         p(bt.to(DEV)), 16, None)
+    torch.cuda.synchronize()
+    for row, s in enumerate(order.tolist()):
+        sc = torch.einsum("hd,shd->hs", q[s].float(), ks[s]) * 0.125
+        ref = torch.einsum("hs,shd->hd", torch.softmax(sc, -1), vs[s]).reshape(-1)
+        assert_bf16_close(out[row], ref, max_ulp=1, max_frac=0.05, what=f"attn_decode ctx={ctxs[s]}")
+    # same row alone in the launch: identical bits
+    one = torch.zeros(1, H * hd, dtype=torch.bfloat16, device=DEV)
+    call(capi, "t3_op_attn_decode", p(qkv_o[2:3].contiguous()), p(one), 1, H, hd, p(order[2:3].to(DEV)), p(ctx_t[2:3].contiguous()),
+         p(pool), layer_stride, 0, p(bt.to(DEV)), 16, None)
+    torch.cuda.synchronize()
+    assert torch.equal(one[0], out[2])
+
+
+def test_attn_prefill_is_causal_per_sequence(capi):
+    H, hd = 16, 64
+    lens = [1, 43, 64, 65, 200]
+    starts = [0]
+    for L in lens:
+        starts.append(starts[-1] + L)
+    N = starts[-1]
+    qkv = _rand((N, 3 * H * hd), 40).to(DEV)
+    out = torch.zeros(N, H * hd, dtype=torch.bfloat16, device=DEV)
+    ss = torch.tensor(starts, dtype=torch.int32)
+    call(capi, "t3_op_attn_prefill", p(qkv), p(out), len(lens), p(ss.to(DEV)), C.cast(ss.data_ptr(), C.POINTER(C.c_int32)),
+         H, hd, None)
+    torch.cuda.synchronize()
+    f = qkv.float()
+    for i, L in enumerate(lens):
+        s0 = starts[i]
+        q = f[s0:s0 + L, :1024].view(L, H, hd)
+        k = f[s0:s0 + L, 1024:2048].view(L, H, hd)
+        v = f[s0:s0 + L, 2048:].view(L, H, hd)
+        sc = torch.einsum("thd,shd->hts", q, k) * 0.125
+        mask = torch.triu(torch.ones(L, L, dtype=torch.bool, device=DEV), 1)
+        sc = sc.masked_fill(mask[None], float("-inf"))
+        ref = torch.einsum("hts,shd->thd", torch.softmax(sc, -1), v).reshape(L, -1)
+        assert_bf16_close(out[s0:s0 + L], ref, max_ulp=1, max_frac=0.05, what=f"attn_prefill len={L}")
+
+
+def test_sampler_cfg_penalty_argmax_is_exact(capi):
+    from oracle.t3_oracle import T3Oracle
+    n, vocab, ldl = 6, 8194, 8208
+    logits = _rand((2 * n, ldl), 50, 2.0).to(DEV)
+    logits[0, 77] = logits[0, 5000] = 30.0                    # a tie: lowest index must win
+    logits[n, 77] = logits[n, 5000] = 1.0
+    row_c = torch.arange(n, dtype=torch.int32)
+    row_u = torch.arange(n, 2 * n, dtype=torch.int32)
+    row_u[3] = -1                                             # one request without CFG
+    seen = torch.zeros(n, 9216, dtype=torch.uint8)
+    g = torch.Generator().manual_seed(51)
+    for i in range(n):
+        seen[i, torch.randint(0, 9194, (300,), generator=g)] = 1
+    seen[0, 1077] = 0; seen[0, 6000] = 0
+    pen = torch.tensor([2.0, 2.0, 1.0, 2.0, 1.3, 2.0])
+    toks = torch.zeros(n, dtype=torch.int32, device=DEV)
+    outl = torch.zeros(n, vocab + 1000, device=DEV)
+    seen_d = seen.to(DEV)
+    cfg_scale = 3.0
+    call(capi, "t3_op_sample_greedy", p(logits), ldl, vocab, p(row_c.to(DEV)), p(row_u.to(DEV)), n, C.c_float(cfg_scale),
+         p(pen.to(DEV)), p(seen_d), 9216, p(toks), p(outl), None)
+    torch.cuda.synchronize()
+    o = T3Oracle.__new__(T3Oracle)
+    o.bf16, o.cfg_scale = True, cfg_scale
+    lc = logits.float().cpu()
+    for i in range(n):
+        u = lc[int(row_u[i]), :vocab] if row_u[i] >= 0 else None
+        full = o.cfg_logits(lc[i, :vocab], u)
+        ref = T3Oracle.apply_repetition_penalty(full, seen[i].nonzero().flatten().tolist(), float(pen[i]))
+        got = outl[i].cpu()
+        assert torch.equal(got, ref), f"request {i}: penalised logits differ"
+        assert int(toks[i]) == T3Oracle.greedy(ref)
+        assert int(seen_d[i, int(toks[i])]) == 1              # chosen column joins the seen set
+    assert int(toks[0]) == 1077

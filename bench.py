@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""Benchmark of the T3 speech-token decode engine (the metric of BASELINE.json).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One STEP = one pass of the whole hot path over one batch of synthetic requests: the
+154-chunk job of the reference's benchmark.py (text-length histogram of
+docs/benchmark-text-1.txt, tests/golden/ref_text_fixture.json) is queued on one engine with 32
+requests decoded concurrently, CFG-paired (cond + uncond stream, scale 3.0), greedy, repetition
+penalty 2.0, prompt + output <= max_model_len 1000.  Random weights never emit the stop token
+reliably, so every request runs to a fixed output length proportional to its text length with
+the README-implied mean of 394 tokens.  Each rank runs the same job on its own GPU (weak
+scaling: requests are independent; the only collective is the final all-gather of ids); value =
+tokens of all ranks / max-over-ranks time.
+
+Besides the throughput line this prints, in the same JSON object:
+  roofline      the dominant kernel's algorithmic bytes / its HIP-event time, measured in a
+                separate pass over the same job with every launch bracketed by events
+  cpu_baseline  the CPU oracle (a port of the same arithmetic) timed on a bounded slice of the job
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from chatterbox_vllm_amd.config import T3ModelConfig, SPEECH_TOKEN_OFFSET  # noqa: E402
+from chatterbox_vllm_amd import weights as W  # noqa: E402
+from chatterbox_vllm_amd.engine import T3Engine, SamplingParams  # noqa: E402
+
+METRIC = "T3 speech-tokens/sec/GPU at batch=32, max_len=1000; 1/2/4/8-GPU scaling"
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak
+MAX_MODEL_LEN = 1000
+CONCURRENCY = 32
+CFG_SCALE = 3.0
+MEAN_OUT = 394                 # README-implied mean speech tokens per chunk (4577.88 tok/s * 13.25 s / 154)
+
+
+def build_job(seed: int, n_requests: int = 0):
+    """(text_ids, out_len) per request of the 154-chunk job."""
+    with open(os.path.join(ROOT, "tests", "golden", "ref_text_fixture.json")) as f:
+        lens = json.load(f)["benchmark_text_1"]["text_id_counts"]
+    if n_requests:
+        lens = lens[:n_requests]
+    mean_t = sum(lens) / len(lens)
+    g = torch.Generator().manual_seed(seed)
+    job = []
+    for T in lens:
+        body = torch.randint(3, 704, (T - 2,), generator=g).tolist()
+        text = [255] + body + [0]                       # [START] ... [STOP]
+        P = 34 + T + 1
+        out = int(round(MEAN_OUT * T / mean_t))
+        out = max(16, min(out, MAX_MODEL_LEN - P))
+        job.append((text, out))
+    return job
+
+
+def run_job(eng: T3Engine, job, cond, stats=None):
+    """Queue the whole job and run the engine dry.  Returns (#tokens, ids per request)."""
+    rids = []
+    for text, out_len in job:
+        sp = SamplingParams(temperature=0.0, repetition_penalty=2.0, max_tokens=out_len, stop_token_ids=None)
+        rids.append(eng.add_request(text, cond, sp))
+    ids = {r: [] for r in rids}
+    n = 0
+    while eng.has_unfinished():
+        for rid, tok, _fin in eng.step():
+            ids[rid].append(tok)
+            n += 1
+        if stats is not None:
+            s = eng.stats()
+            if s.decode_requests:
+                stats["decode_steps"] += 1
+                stats["decode_rows"] += s.decode_rows
+                stats["decode_ctx_tokens"] += s.decode_ctx_tokens
+    return n, [ids[r] for r in rids]
+
+
+def cpu_baseline(cfg, sd, job, cond):
+    """The oracle on a bounded slice: 4 requests of the job (the 4 shortest texts), CFG-paired,
+    prefill + 12 greedy tokens each, batched decode steps."""
+    from oracle.t3_oracle import T3Oracle
+    torch.set_num_threads(max(1, min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))))
+    o = T3Oracle(sd, n_layers=cfg.n_layers, cfg_scale=CFG_SCALE)
+    sub = sorted(job, key=lambda t: len(t[0]))[:4]
+    reqs = [(t, cond) for t, _ in sub]
+    t0 = time.time()
+    out = o.generate_batch(reqs, [12] * len(reqs))
+    dt = time.time() - t0
+    ntok = sum(len(x) for x in out)
+    return {"value": round(ntok / dt, 3), "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{len(reqs)} shortest requests of the job (text ids {[len(t) for t, _ in sub]}), CFG-paired, "
+                      f"prefill + 12 greedy tokens each, batched decode, {dt:.1f} s of CPU time"}, out, sub
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--requests", type=int, default=0, help="use only the first N requests of the job (debug)")
+    ap.add_argument("--layers", type=int, default=30, help="debug only: anything but 30 is not the benchmark")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    cfg = T3ModelConfig.english(n_layers=args.layers)
+    sd = W.synthetic_state_dict(cfg, seed=1234)
+    if dist is not None:
+        # rank 0's checkpoint is the checkpoint: one RCCL broadcast of the weights over xGMI
+        from chatterbox_vllm_amd.sharding import broadcast_state_dict
+        sd = broadcast_state_dict(sd, src=0, device=torch.device("cuda", local_rank))
+    cond = W.synthetic_cond_emb(0)
+    job = build_job(seed=7 + rank, n_requests=args.requests)
+    eng = T3Engine(cfg, sd, max_model_len=MAX_MODEL_LEN, max_num_seqs=CONCURRENCY, cfg_scale=CFG_SCALE,
+                   cfg_paired=True, device=local_rank, max_prefill_rows=2048)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(local_rank)
+
+    for _ in range(args.warmup):
+        run_job(eng, job, cond)
+    stats = {"decode_steps": 0, "decode_rows": 0, "decode_ctx_tokens": 0}
+    barrier()
+    t0 = time.perf_counter()
+    tokens = 0
+    last_ids = None
+    for _ in range(args.steps):
+        n, last_ids = run_job(eng, job, cond, stats)
+        tokens += n
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=f"cuda:{local_rank}", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        tk = torch.tensor([tokens], device=f"cuda:{local_rank}", dtype=torch.int64)
+        dist.all_reduce(tk, op=dist.ReduceOp.SUM)
+        total_tokens = int(tk.item())
+        # the job's result travels to rank 0 the way a sharded generate() returns it
+        from chatterbox_vllm_amd.sharding import gather_token_ids
+        gathered = gather_token_ids(last_ids, device=torch.device("cuda", local_rank))
+        assert rank != 0 or len(gathered) == world * len(job)
+    else:
+        total_tokens = tokens
+
+    result = None
+    if rank == 0:
+        result = {
+            "metric": METRIC, "value": round(total_tokens / dt, 2), "unit": "tokens/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000 * dt / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "benchmark.py 154-chunk job (docs/benchmark-text-1.txt length histogram), "
+                                   "32 concurrent requests, CFG-paired scale 3.0, greedy, max_model_len 1000, "
+                                   f"output length ~ text length with mean {MEAN_OUT}; per GPU",
+                       "requests_per_gpu": len(job), "tokens_per_step_per_gpu": tokens // max(1, args.steps),
+                       "concurrency": CONCURRENCY, "layers": cfg.n_layers, "parallelism": f"request-sharded x{world}"},
+            "per_gpu_tokens_per_s": round(total_tokens / dt / world, 2),
+            "decode": {"steps": stats["decode_steps"],
+                       "mean_rows": round(stats["decode_rows"] / max(1, stats["decode_steps"]), 2),
+                       "mean_ctx": round(stats["decode_ctx_tokens"] / max(1, stats["decode_rows"]), 1)},
+        }
+
+    # ---- roofline: per-launch event timing of every kernel class over one more pass of the job
+    if rank == 0 and not args.no_roofline:
+        eng.set_kernel_timing(True)
+        t1 = time.perf_counter()
+        run_job(eng, job, cond)
+        timed_pass = time.perf_counter() - t1
+        kd, kp = eng.kernel_times("decode"), eng.kernel_times("prefill")
+        eng.set_kernel_timing(False)
+        tot = sum(v["ms"] for v in kd.values()) + sum(v["ms"] for v in kp.values())
+        name, dom = max(kd.items(), key=lambda kv: kv[1]["ms"])
+        per_launch_bytes = dom["bytes"] / dom["launches"]
+        per_launch_s = dom["ms"] / dom["launches"] / 1000.0
+        achieved = per_launch_bytes / per_launch_s / 1e9
+        result["roofline"] = {
+            "bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "avg_launch_us": round(per_launch_s * 1e6, 2), "algorithmic_bytes_per_launch": int(per_launch_bytes),
+            "launches": dom["launches"], "share_of_gpu_time": round(dom["ms"] / tot, 3),
+        }
+        result["kernel_breakdown"] = {
+            ph: {k: {"ms": round(v["ms"], 2), "launches": v["launches"],
+                     "GBps": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1)} for k, v in d.items()}
+            for ph, d in (("decode", kd), ("prefill", kp))}
+        result["kernel_breakdown"]["event_timed_pass_s"] = round(timed_pass, 3)
+    eng.shutdown()
+
+    if rank == 0 and not args.no_cpu_baseline:
+        cb, cpu_ids, sub = cpu_baseline(cfg, sd, job, cond)
+        result["cpu_baseline"] = cb
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

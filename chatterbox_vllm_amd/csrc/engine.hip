@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <map>
@@ -57,6 +58,13 @@ struct Request {
 struct Layer {
     bf16_t *ln1 = nullptr, *ln2 = nullptr, *wqkv = nullptr, *wo = nullptr, *wgu = nullptr, *wd = nullptr;
 };
+
+// kernel classes for the per-launch event timing mode
+enum KClass { K_EMBED, K_NORM, K_QKV, K_ATTN_DECODE, K_ATTN_PREFILL, K_OPROJ, K_GATEUP, K_DOWN, K_HEAD, K_SAMPLE,
+              K_SEEN, K_NCLASS };
+const char* const kClassName[K_NCLASS] = {"embed", "add_rmsnorm", "gemm_qkv_rope", "attn_decode", "attn_prefill",
+                                          "gemm_o_resid", "gemm_gateup_silu", "gemm_down_resid", "gemm_head",
+                                          "sample", "seen_init"};
 
 template <typename T>
 struct Pinned {
@@ -99,6 +107,7 @@ struct t3_engine {
 
     // activations
     int max_rows = 0;
+    int64_t cur_ctx_tokens = 0;                         // sum of context lengths of the decode rows of this step
     bf16_t *res = nullptr, *xn = nullptr, *qkv = nullptr, *att = nullptr, *hbuf = nullptr, *logits = nullptr;
     float* cond_buf = nullptr;                          // [max_num_seqs][34][d] fp32
     uint8_t* seen = nullptr;                            // [max_num_seqs][kSeenStride]
@@ -124,6 +133,18 @@ struct t3_engine {
 
     t3_step_stats stats{};
     bool timing = false;
+    bool debug_sync = false;
+
+    // per-launch event timing (t3_engine_set_kernel_timing): [phase 0 decode / 1 prefill][class]
+    bool ktiming = false;
+    int kphase = 0;
+    std::vector<hipEvent_t> kpool;
+    struct KPending { int phase, cls, ev; int64_t bytes; };
+    std::vector<KPending> kpending;
+    size_t kused = 0;
+    double kms[2][K_NCLASS] = {};
+    int64_t klaunches[2][K_NCLASS] = {};
+    int64_t kbytes[2][K_NCLASS] = {};
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 
     KvView kvview() const {
@@ -136,6 +157,19 @@ namespace {
 
 template <typename T>
 T* carve(T*& base, size_t n) { T* p = base; base += n; return p; }
+
+// With T3_DEBUG_SYNC=1 every launch is followed by a synchronize, so a faulting kernel is named.
+// In kernel-timing mode every launch is bracketed by two HIP events on the engine's stream.
+int stage_check(t3_engine* e, const char* label, int layer = -1);
+int ktime_begin(t3_engine* e, int cls, int64_t bytes);
+int ktime_end(t3_engine* e);
+#define T3_RUN(e, cls, layer, bytes, call)                              \
+    do {                                                                \
+        if (ktime_begin(e, cls, bytes)) return 1;                       \
+        if (call) return 1;                                             \
+        if (ktime_end(e)) return 1;                                     \
+        if (stage_check(e, kClassName[cls], layer)) return 1;           \
+    } while (0)
 
 int meta_alloc(t3_engine::Meta& m, size_t rows, size_t reqs, size_t prompt_ids) {
     m.rows_cap = rows; m.req_cap = reqs;
@@ -165,6 +199,51 @@ int upload(t3_engine* e, t3_engine::Meta& m) {
     return 0;
 }
 
+int stage_check(t3_engine* e, const char* label, int layer) {
+    if (!e->debug_sync) return 0;
+    const hipError_t err = hipStreamSynchronize(e->stream);
+    if (err != hipSuccess) {
+        t3_set_error(std::string("stage ") + label + (layer >= 0 ? " layer " + std::to_string(layer) : std::string()) +
+                     ": " + hipGetErrorString(err));
+        return 1;
+    }
+    return 0;
+}
+
+int ktime_begin(t3_engine* e, int cls, int64_t bytes) {
+    if (!e->ktiming) return 0;
+    if (e->kused + 2 > e->kpool.size()) {
+        const size_t want = e->kpool.size() + 1024;
+        while (e->kpool.size() < want) {
+            hipEvent_t ev;
+            T3_HIP_CHECK(hipEventCreate(&ev));
+            e->kpool.push_back(ev);
+        }
+    }
+    e->kpending.push_back({e->kphase, cls, (int)e->kused, bytes});
+    T3_HIP_CHECK(hipEventRecord(e->kpool[e->kused], e->stream));
+    return 0;
+}
+int ktime_end(t3_engine* e) {
+    if (!e->ktiming) return 0;
+    T3_HIP_CHECK(hipEventRecord(e->kpool[e->kused + 1], e->stream));
+    e->kused += 2;
+    return 0;
+}
+// after the step's synchronize: fold the event pairs into the per-class totals
+int ktime_collect(t3_engine* e) {
+    for (const auto& p : e->kpending) {
+        float ms = 0.f;
+        T3_HIP_CHECK(hipEventElapsedTime(&ms, e->kpool[p.ev], e->kpool[p.ev + 1]));
+        e->kms[p.phase][p.cls] += ms;
+        e->klaunches[p.phase][p.cls] += 1;
+        e->kbytes[p.phase][p.cls] += p.bytes;
+    }
+    e->kpending.clear();
+    e->kused = 0;
+    return 0;
+}
+
 int dmalloc(bf16_t** p, size_t elems) { T3_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(p), elems * sizeof(bf16_t))); return 0; }
 
 // ---- the layer stack over `rows` rows whose embeddings are already in e->res ----------
@@ -176,28 +255,28 @@ int run_layers(t3_engine* e, int rows, const int32_t* d_pos, const int32_t* d_st
     const KvView kv = e->kvview();
     for (int li = 0; li < c.n_layers; ++li) {
         const Layer& L = e->layers[li];
-        if (launch_add_rmsnorm(nullptr, e->res, L.ln1, e->xn, rows, D, c.rms_eps, st)) return 1;
+        T3_RUN(e, K_NORM, li, 4LL * rows * D, launch_add_rmsnorm(nullptr, e->res, L.ln1, e->xn, rows, D, c.rms_eps, st));
         GemmArgs g{};
         g.A = e->xn; g.lda = D; g.Wt = L.wqkv; g.C = e->qkv; g.ldc = 3 * D; g.M = rows; g.N = 3 * D; g.K = D;
         g.n_valid = 3 * D; g.rope = e->rope; g.pos = d_pos; g.row_stream = d_stream; g.kv = kv; g.layer = li;
-        if (launch_gemm(EPI_QKV_ROPE, g, st)) return 1;
+        T3_RUN(e, K_QKV, li, 2LL * 3 * D * D, launch_gemm(EPI_QKV_ROPE, g, st));
         if (prefill) {
-            if (launch_attn_prefill(e->qkv, 3 * D, e->att, d_seq_start, d_tiles, ntiles, H, hd, st)) return 1;
+            T3_RUN(e, K_ATTN_PREFILL, li, 2LL * rows * 4 * D, launch_attn_prefill(e->qkv, 3 * D, e->att, d_seq_start, d_tiles, ntiles, H, hd, st));
         } else {
-            if (launch_attn_decode(e->qkv, 3 * D, e->att, rows, d_stream, d_ctx, kv, li, st)) return 1;
+            T3_RUN(e, K_ATTN_DECODE, li, e->cur_ctx_tokens * 4LL * D, launch_attn_decode(e->qkv, 3 * D, e->att, rows, d_stream, d_ctx, kv, li, st));
         }
         GemmArgs o{};
         o.A = e->att; o.lda = D; o.Wt = L.wo; o.C = e->res; o.ldc = D; o.M = rows; o.N = D; o.K = D; o.n_valid = D;
-        if (launch_gemm(EPI_RESID, o, st)) return 1;
-        if (launch_add_rmsnorm(nullptr, e->res, L.ln2, e->xn, rows, D, c.rms_eps, st)) return 1;
+        T3_RUN(e, K_OPROJ, li, 2LL * D * D, launch_gemm(EPI_RESID, o, st));
+        T3_RUN(e, K_NORM, li, 4LL * rows * D, launch_add_rmsnorm(nullptr, e->res, L.ln2, e->xn, rows, D, c.rms_eps, st));
         GemmArgs u{};
         u.A = e->xn; u.lda = D; u.Wt = L.wgu; u.C = e->hbuf; u.ldc = F; u.M = rows; u.N = 2 * F; u.K = D; u.n_valid = 2 * F;
-        if (launch_gemm(EPI_SILU, u, st)) return 1;
+        T3_RUN(e, K_GATEUP, li, 2LL * 2 * F * D, launch_gemm(EPI_SILU, u, st));
         GemmArgs dn{};
         dn.A = e->hbuf; dn.lda = F; dn.Wt = L.wd; dn.C = e->res; dn.ldc = D; dn.M = rows; dn.N = D; dn.K = F; dn.n_valid = D;
-        if (launch_gemm(EPI_RESID, dn, st)) return 1;
+        T3_RUN(e, K_DOWN, li, 2LL * F * D, launch_gemm(EPI_RESID, dn, st));
     }
-    if (launch_add_rmsnorm(nullptr, e->res, e->norm_w, e->xn, rows, D, c.rms_eps, st)) return 1;
+    T3_RUN(e, K_NORM, -1, 4LL * rows * D, launch_add_rmsnorm(nullptr, e->res, e->norm_w, e->xn, rows, D, c.rms_eps, st));
     return 0;
 }
 
@@ -206,7 +285,7 @@ int run_head_and_sample(t3_engine* e, t3_engine::Meta& m, int head_rows, const i
     GemmArgs g{};
     g.A = e->xn; g.lda = c.d_model; g.a_rows = d_a_rows; g.Wt = e->head; g.C = e->logits; g.ldc = e->head_n;
     g.M = head_rows; g.N = e->head_n; g.K = c.d_model; g.n_valid = e->head_n;
-    if (launch_gemm(EPI_STORE, g, e->stream)) return 1;
+    T3_RUN(e, K_HEAD, -1, 2LL * e->head_n * c.d_model, launch_gemm(EPI_STORE, g, e->stream));
     SampleArgs s{};
     s.logits = e->logits; s.ldl = e->head_n; s.vocab = c.speech_vocab;
     s.row_c = dev_of(m.i32, m.row_c); s.row_u = dev_of(m.i32, m.row_u); s.slot = dev_of(m.i32, m.slot);
@@ -217,7 +296,8 @@ int run_head_and_sample(t3_engine* e, t3_engine::Meta& m, int head_rows, const i
     s.seen = e->seen; s.seen_stride = kSeenStride; s.last_token = e->last_token;
     s.out_tokens = dev_of(m.i32, m.out_tokens);
     s.out_logits = e->keep_logits ? e->dbg_logits : nullptr;
-    return launch_sample(s, e->stream);
+    T3_RUN(e, K_SAMPLE, -1, 4LL * n_req * c.speech_vocab, launch_sample(s, e->stream));
+    return 0;
 }
 
 void fill_sampling(t3_engine::Meta& m, int i, const Request& r) {
@@ -304,14 +384,16 @@ int run_prefill(t3_engine* e, const std::vector<Request*>& reqs) {
     }
     m.seq_start[nseq] = row;
     const int rows = row;
+    e->kphase = 1;
     if (sync_block_table(e)) return 1;
     if (upload(e, m)) return 1;
+    if (stage_check(e, "prefill_upload")) return 1;
     // seen rows
     pid = 0;
     for (int i = 0; i < n; ++i) {
         const int len = reqs[i]->prompt_len;
-        if (launch_seen_init(e->seen + (size_t)reqs[i]->slot * kSeenStride, kSeenStride,
-                             dev_of(m.i32, m.prompt_ids) + pid, len, e->stream)) return 1;
+        T3_RUN(e, K_SEEN, -1, (int64_t)kSeenStride, launch_seen_init(e->seen + (size_t)reqs[i]->slot * kSeenStride, kSeenStride,
+                                                     dev_of(m.i32, m.prompt_ids) + pid, len, e->stream));
         pid += len;
     }
     EmbedArgs ea{};
@@ -319,7 +401,7 @@ int run_prefill(t3_engine* e, const std::vector<Request*>& reqs) {
     ea.kind = dev_of(m.i32, m.ekind); ea.idx = dev_of(m.i32, m.eidx); ea.aux = dev_of(m.i32, m.eaux);
     ea.cond = e->cond_buf; ea.text_emb = e->text_emb; ea.text_pos = e->text_pos;
     ea.speech_emb = e->speech_emb; ea.speech_pos = e->speech_pos; ea.last_token = e->last_token; ea.sos_id = kSOS;
-    if (launch_embed(ea, e->stream)) return 1;
+    T3_RUN(e, K_EMBED, -1, 2LL * rows * c.d_model, launch_embed(ea, e->stream));
     if (run_layers(e, rows, dev_of(m.i32, m.row_pos), dev_of(m.i32, m.row_stream), dev_of(m.i32, m.row_ctx), true,
                    dev_of(m.i32, m.seq_start), dev_of(m.i32, m.tiles), ntiles)) return 1;
     if (run_head_and_sample(e, m, n * S, dev_of(m.i32, m.a_rows), n)) return 1;
@@ -338,7 +420,7 @@ int enqueue_decode(t3_engine* e, int B) {
     ea.kind = dev_of(m.i32, m.ekind); ea.idx = dev_of(m.i32, m.eidx); ea.aux = dev_of(m.i32, m.eaux);
     ea.cond = e->cond_buf; ea.text_emb = e->text_emb; ea.text_pos = e->text_pos;
     ea.speech_emb = e->speech_emb; ea.speech_pos = e->speech_pos; ea.last_token = e->last_token; ea.sos_id = kSOS;
-    if (launch_embed(ea, e->stream)) return 1;
+    T3_RUN(e, K_EMBED, -1, 2LL * rows * c.d_model, launch_embed(ea, e->stream));
     if (run_layers(e, rows, dev_of(m.i32, m.row_pos), dev_of(m.i32, m.row_stream), dev_of(m.i32, m.row_ctx), false,
                    nullptr, nullptr, 0)) return 1;
     return run_head_and_sample(e, m, rows, nullptr, B);
@@ -366,7 +448,9 @@ int run_decode(t3_engine* e, const std::vector<Request*>& reqs) {
     }
     if (sync_block_table(e)) return 1;
     if (upload(e, m)) return 1;
-    const bool graphs = e->cfg.use_graphs && !e->keep_logits;
+    e->cur_ctx_tokens = ctx_total;
+    e->kphase = 0;
+    const bool graphs = e->cfg.use_graphs && !e->keep_logits && !e->debug_sync && !e->ktiming;
     if (graphs && e->rows_seen[B]++ >= 1) {
         auto it = e->graphs.find(B);
         if (it == e->graphs.end()) {
@@ -423,6 +507,8 @@ extern "C" int t3_engine_create(const t3_config* cfg, t3_engine** out) {
     T3_HIP_CHECK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     e->layers.resize(c.n_layers);
     e->slots.resize(c.max_num_seqs);
+    const char* dbg = getenv("T3_DEBUG_SYNC");
+    e->debug_sync = dbg && dbg[0] == '1';
 
     // KV pool
     e->n_pages = c.kv_pages > 0 ? c.kv_pages : (int64_t)e->n_streams * e->max_pages;
@@ -561,6 +647,7 @@ extern "C" int t3_engine_destroy(t3_engine* e) {
     e->block_table.release();
     for (auto* m : {&e->dm, &e->pm}) { m->i32.release(); m->f32.release(); m->u64.release(); }
     for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
+    for (auto& ev : e->kpool) (void)hipEventDestroy(ev);
     (void)hipStreamDestroy(e->stream);
     delete e;
     return 0;
@@ -621,6 +708,28 @@ extern "C" int t3_engine_get_stats(t3_engine* e, t3_step_stats* out) {
 extern "C" int t3_engine_set_timing(t3_engine* e, int32_t on) {
     T3_REQUIRE(e, "null argument");
     e->timing = on != 0;
+    return 0;
+}
+
+extern "C" int t3_engine_set_kernel_timing(t3_engine* e, int32_t on) {
+    T3_REQUIRE(e, "null argument");
+    e->ktiming = on != 0;
+    if (on) {
+        std::memset(e->kms, 0, sizeof(e->kms));
+        std::memset(e->klaunches, 0, sizeof(e->klaunches));
+        std::memset(e->kbytes, 0, sizeof(e->kbytes));
+    }
+    return 0;
+}
+
+extern "C" int t3_kernel_class_count(void) { return K_NCLASS; }
+extern "C" const char* t3_kernel_class_name(int32_t cls) { return cls >= 0 && cls < K_NCLASS ? kClassName[cls] : ""; }
+
+extern "C" int t3_engine_get_kernel_times(t3_engine* e, int32_t phase, double* ms, int64_t* launches, int64_t* bytes,
+                                          int32_t n) {
+    T3_REQUIRE(e && ms && launches && bytes, "null argument");
+    T3_REQUIRE((phase == 0 || phase == 1) && n >= K_NCLASS, "bad phase or array too small");
+    for (int i = 0; i < K_NCLASS; ++i) { ms[i] = e->kms[phase][i]; launches[i] = e->klaunches[phase][i]; bytes[i] = e->kbytes[phase][i]; }
     return 0;
 }
 
@@ -688,6 +797,7 @@ extern "C" int t3_engine_step(t3_engine* e, int64_t* out_req_ids, int32_t* out_t
                                     hipMemcpyDeviceToHost, e->stream));
     }
     T3_HIP_CHECK(hipStreamSynchronize(e->stream));
+    if (e->ktiming && ktime_collect(e)) return 1;
     if (e->timing) {
         if (!admitted.empty()) T3_HIP_CHECK(hipEventElapsedTime(&e->stats.prefill_gpu_ms, e->ev[0], e->ev[1]));
         if (!running.empty()) T3_HIP_CHECK(hipEventElapsedTime(&e->stats.decode_gpu_ms, e->ev[2], e->ev[3]));

@@ -71,29 +71,53 @@ int launch_add_rmsnorm(const bf16_t* x, bf16_t* res, const bf16_t* w, bf16_t* xn
 // Embedding rows.  kind 0: conditioning row (fp32 -> bf16); 1: text_emb[id] + text_pos[p];
 // 2: zeros (uncond text row); 3: speech_emb[SOS] + speech_pos[0]; 4: speech_emb[last_token[slot]].
 // ------------------------------------------------------------------------------------
+// Each row kind is a straight-line body with its own store: a shared store after a chain of
+// branches was miscompiled by hipcc 7.2 (the store's column register was left undefined on one
+// path), so no value is carried across the kind dispatch.
+__device__ __forceinline__ void embed_sum_row(bf16_t* __restrict__ dst, const bf16_t* __restrict__ e,
+                                              const bf16_t* __restrict__ p, int d) {
+    for (int c = threadIdx.x * 8; c < d; c += 128 * 8) {
+        const u32x4 ev = *reinterpret_cast<const u32x4*>(e + c);
+        const u32x4 pv = *reinterpret_cast<const u32x4*>(p + c);
+        u32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = pack_bf2(bf_lo(ev[i]) + bf_lo(pv[i]), bf_hi(ev[i]) + bf_hi(pv[i]));
+        *reinterpret_cast<u32x4*>(dst + c) = o;
+    }
+}
+
 __global__ __launch_bounds__(128) void embed_kernel(EmbedArgs a) {
     const size_t row = blockIdx.x;
-    const int kind = a.kind[row], idx = a.idx[row], aux = a.aux[row];
-    for (int c = threadIdx.x * 8; c < a.d; c += 128 * 8) {
-        u32x4 o = {0u, 0u, 0u, 0u};
-        if (kind == 0) {
-            const float* src = a.cond + ((size_t)aux * 34 + idx) * a.d + c;
-            const f32x4 v0 = *reinterpret_cast<const f32x4*>(src);
-            const f32x4 v1 = *reinterpret_cast<const f32x4*>(src + 4);
-            o[0] = pack_bf2(v0[0], v0[1]); o[1] = pack_bf2(v0[2], v0[3]);
-            o[2] = pack_bf2(v1[0], v1[1]); o[3] = pack_bf2(v1[2], v1[3]);
-        } else if (kind == 1 || kind == 3) {
-            const bf16_t* e = kind == 1 ? a.text_emb + (size_t)idx * a.d : a.speech_emb + (size_t)a.sos_id * a.d;
-            const bf16_t* p = kind == 1 ? a.text_pos + (size_t)aux * a.d : a.speech_pos;
-            const u32x4 ev = *reinterpret_cast<const u32x4*>(e + c);
-            const u32x4 pv = *reinterpret_cast<const u32x4*>(p + c);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) o[i] = pack_bf2(bf_lo(ev[i]) + bf_lo(pv[i]), bf_hi(ev[i]) + bf_hi(pv[i]));
-        } else if (kind == 4) {
-            o = *reinterpret_cast<const u32x4*>(a.speech_emb + (size_t)a.last_token[idx] * a.d + c);
+    const int kind = __builtin_amdgcn_readfirstlane(a.kind[row]);
+    const int idx = __builtin_amdgcn_readfirstlane(a.idx[row]);
+    const int aux = __builtin_amdgcn_readfirstlane(a.aux[row]);
+    bf16_t* dst = a.out + row * a.d;
+    if (kind == 0) {
+        const float* src = a.cond + ((size_t)aux * 34 + idx) * a.d;
+        for (int c = threadIdx.x * 8; c < a.d; c += 128 * 8) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(src + c);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(src + c + 4);
+            const u32x4 o = {pack_bf2(v0[0], v0[1]), pack_bf2(v0[2], v0[3]), pack_bf2(v1[0], v1[1]), pack_bf2(v1[2], v1[3])};
+            *reinterpret_cast<u32x4*>(dst + c) = o;
         }
-        *reinterpret_cast<u32x4*>(a.out + row * a.d + c) = o;
+        return;
     }
+    if (kind == 1) {
+        embed_sum_row(dst, a.text_emb + (size_t)idx * a.d, a.text_pos + (size_t)aux * a.d, a.d);
+        return;
+    }
+    if (kind == 3) {
+        embed_sum_row(dst, a.speech_emb + (size_t)a.sos_id * a.d, a.speech_pos, a.d);
+        return;
+    }
+    if (kind == 4) {
+        const bf16_t* src = a.speech_emb + (size_t)a.last_token[idx] * a.d;
+        for (int c = threadIdx.x * 8; c < a.d; c += 128 * 8)
+            *reinterpret_cast<u32x4*>(dst + c) = *reinterpret_cast<const u32x4*>(src + c);
+        return;
+    }
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+    for (int c = threadIdx.x * 8; c < a.d; c += 128 * 8) *reinterpret_cast<u32x4*>(dst + c) = zero;
 }
 
 int launch_embed(const EmbedArgs& a, hipStream_t st) {

@@ -161,6 +161,18 @@ class T3Engine:
     def set_timing(self, on: bool) -> None:
         _capi.check(self._lib, self._lib.t3_engine_set_timing(self._h, int(on)))
 
+    def set_kernel_timing(self, on: bool) -> None:
+        """Bracket every kernel launch with HIP events (eager launches while on)."""
+        _capi.check(self._lib, self._lib.t3_engine_set_kernel_timing(self._h, int(on)))
+
+    def kernel_times(self, phase: str = "decode") -> Dict[str, dict]:
+        """{class: {"ms": total, "launches": n, "bytes": algorithmic bytes}} since timing was switched on."""
+        n = self._lib.t3_kernel_class_count()
+        ms, cnt, byt = (C.c_double * n)(), (C.c_int64 * n)(), (C.c_int64 * n)()
+        _capi.check(self._lib, self._lib.t3_engine_get_kernel_times(self._h, 0 if phase == "decode" else 1, ms, cnt, byt, n))
+        return {self._lib.t3_kernel_class_name(i).decode(): {"ms": ms[i], "launches": cnt[i], "bytes": byt[i]}
+                for i in range(n) if cnt[i]}
+
     def set_keep_logits(self, on: bool) -> None:
         _capi.check(self._lib, self._lib.t3_engine_set_keep_logits(self._h, int(on)))
 

@@ -99,6 +99,18 @@ int t3_engine_get_stats(t3_engine* e, t3_step_stats* out);
 /* Enable HIP-event timing of the prefill / decode parts of each step (adds a sync). */
 int t3_engine_set_timing(t3_engine* e, int32_t on);
 
+/* ---- measurement: per-launch HIP-event timing by kernel class.  While on, decode steps are
+ *      launched eagerly (no graph replay) and every kernel launch is bracketed by two events on
+ *      the engine's stream; totals accumulate until the next t3_engine_set_kernel_timing(e, 1).
+ *      No counterpart in the reference (its only timing is wall clock around LLM.generate,
+ *      src/chatterbox_vllm/tts.py:407-420). ------------------------------------------------- */
+int t3_engine_set_kernel_timing(t3_engine* e, int32_t on);
+int t3_kernel_class_count(void);
+const char* t3_kernel_class_name(int32_t cls);
+/* phase 0 = decode steps, 1 = prefill.  Arrays of n >= t3_kernel_class_count() entries:
+ * total milliseconds, launches, and algorithmic bytes (weights or KV a launch must read). */
+int t3_engine_get_kernel_times(t3_engine* e, int32_t phase, double* ms, int64_t* launches, int64_t* bytes, int32_t n);
+
 /* ---- debugging taps for parity tests ------------------------------------------- */
 /* Keep the CFG-combined, penalised fp32 logits of every sampled token (turns graph replay
  * off).  The logits are what models/t3/t3.py:725-739 returns, after the sampler's

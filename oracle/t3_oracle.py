@@ -215,6 +215,79 @@ class T3Oracle:
             res = self.r(x + res)
         return self._rms(res, self.norm_w)
 
+    def forward_decode_rows(self, x: torch.Tensor, pos: Sequence[int], streams: Sequence[_Stream]) -> torch.Tensor:
+        """One decode token for R different streams at once (row r belongs to streams[r] at
+        position pos[r]).  Same arithmetic as ``forward`` row by row; the projections run as one
+        [R, d] matmul, which is how a batched CPU implementation would serve a batch."""
+        R = x.shape[0]
+        pos_t = torch.tensor(list(pos), dtype=torch.long)
+        res = None
+        for li, lw in enumerate(self.layers):
+            res = x if res is None else self.r(x + res)
+            xn = self._rms(res, lw["ln1"])
+            qkv = self.r(xn @ lw["wqkv"].T)
+            q, k, v = qkv.split(self.d, dim=-1)
+            q = self._rope(q.view(R, self.H, self.hd), pos_t)
+            k = self._rope(k.view(R, self.H, self.hd), pos_t)
+            v = v.reshape(R, self.H, self.hd)
+            rows = []
+            for r_, st in enumerate(streams):
+                st.k[li] = torch.cat([st.k[li], k[r_:r_ + 1]], 0)
+                st.v[li] = torch.cat([st.v[li], v[r_:r_ + 1]], 0)
+                if st.attends:
+                    sc = torch.einsum("hd,shd->hs", q[r_], st.k[li]) * 0.125
+                    rows.append(torch.einsum("hs,shd->hd", torch.softmax(sc, -1), st.v[li]).reshape(self.d))
+                else:
+                    rows.append(torch.zeros(self.d))
+            a = self.r(torch.stack(rows))
+            x = self.r(a @ lw["wo"].T)
+            res = self.r(x + res)
+            xn = self._rms(res, lw["ln2"])
+            gu = self.r(xn @ lw["wgu"].T)
+            g, u = gu.split(self.ff, dim=-1)
+            x = self.r(self.r(self.r(g / (1.0 + torch.exp(-g))) * u) @ lw["wd"].T)
+        res = x if res is None else self.r(x + res)
+        return self._rms(res, self.norm_w)
+
+    def generate_batch(self, requests: Sequence[Tuple[Sequence[int], torch.Tensor]], out_lens: Sequence[int],
+                       repetition_penalty: float = 2.0, paired: bool = True) -> List[List[int]]:
+        """Greedy ids for a batch served together: per-request prefill, then batched decode steps
+        (rows = cond streams then uncond streams).  Used as the timed CPU baseline."""
+        n = len(requests)
+        sc = [_Stream() for _ in range(n)]
+        su = [_Stream(attends=self.uncond_attends) for _ in range(n)]
+        hc, hu, P, seen, out = [], [], [], [], [[] for _ in range(n)]
+        for i, (text, cond) in enumerate(requests):
+            ce, ue = self.prefill_embeds(text, cond)
+            p = torch.arange(ce.shape[0])
+            hc.append(self.forward(ce, p, sc[i])[-1])
+            hu.append(self.forward(ue, p, su[i])[-1] if paired else None)
+            P.append(ce.shape[0])
+            seen.append(list(build_prompt_ids(text)))
+        active = list(range(n))
+        while active:
+            lc = self.head_logits(torch.stack([hc[i] for i in active]))
+            lu = self.head_logits(torch.stack([hu[i] for i in active])) if paired else None
+            logits = self.cfg_logits(lc, lu)
+            for j, i in enumerate(active):
+                tok = self.greedy(self.apply_repetition_penalty(logits[j], seen[i], repetition_penalty))
+                out[i].append(tok)
+                seen[i].append(tok)
+            active = [i for i in active if len(out[i]) < out_lens[i]]
+            if not active:
+                break
+            e = self.r(torch.cat([self.decode_embed(out[i][-1]) for i in active]))
+            pos = [P[i] + len(out[i]) - 1 for i in active]
+            if paired:
+                h = self.forward_decode_rows(torch.cat([e, e]), pos + pos, [sc[i] for i in active] + [su[i] for i in active])
+                for j, i in enumerate(active):
+                    hc[i], hu[i] = h[j], h[len(active) + j]
+            else:
+                h = self.forward_decode_rows(e, pos, [sc[i] for i in active])
+                for j, i in enumerate(active):
+                    hc[i] = h[j]
+        return out
+
     # ---- logits ---------------------------------------------------------------
     def head_logits(self, h: torch.Tensor) -> torch.Tensor:
         return self.r(h @ self.head.T)

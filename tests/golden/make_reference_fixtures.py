@@ -158,6 +158,21 @@ def main():
             out[f"{tag}_hidden"] = _bits(hid)
             out[f"{tag}_logits"] = _bits(lg)
             out[f"{tag}_cfg_scale"] = np.float32(m.cfg_scale)
+    # ---- conditioning encoder: reference T3CondEnc on the seeded cond_enc.* weights -------
+    from chatterbox_vllm.models.t3.modules.cond_enc import T3Cond, T3CondEnc
+    from chatterbox_vllm.models.t3.modules.t3_config import T3Config
+    from chatterbox_vllm_amd import cond_enc as CE
+    with torch.inference_mode():
+        enc = T3CondEnc(T3Config()).eval()
+        enc.load_state_dict({k[len("cond_enc."):]: v for k, v in CE.synthetic_weights(1234).items()})
+        g = torch.Generator().manual_seed(31)
+        spk = torch.randn(1, 256, generator=g)
+        prompt = torch.randn(150, 1024, generator=g) * 0.05
+        for e in (0.5, 0.8):
+            ref = enc(T3Cond(speaker_emb=spk, cond_prompt_speech_tokens=torch.zeros(1, 150, dtype=torch.long),
+                             cond_prompt_speech_emb=prompt, emotion_adv=e * torch.ones(1, 1)))
+            out[f"condenc_out_{e}"] = ref.float().numpy().astype(np.float32)
+        out["condenc_emotion_row_0.3"] = enc.emotion_adv_fc(0.3 * torch.ones(1, 1))[0].float().numpy()
     np.savez_compressed(os.path.join(HERE, "ref_plugin_fixture.npz"), **out)
     print("wrote ref_plugin_fixture.npz:", {k: v.shape for k, v in out.items() if hasattr(v, "shape")})
 

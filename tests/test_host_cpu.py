@@ -1,0 +1,174 @@
+"""Host-side logic on the CPU: text normalisation, tokenizers, id post-processing, the
+conditioning encoder, checkpoint routing, and request sharding over a world-size-2 gloo group.
+Expected values come from tests/golden (captured from the reference by make_reference_fixtures.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from chatterbox_vllm_amd import cond_enc as CE
+from chatterbox_vllm_amd import weights as W
+from chatterbox_vllm_amd.config import T3ModelConfig
+from chatterbox_vllm_amd.text_utils import punc_norm, guard_cap, batch_max_tokens, nonspace_chars
+
+REF_EN_VOCAB = "/root/reference/src/chatterbox_vllm/models/t3/tokenizer.json"
+REF_MTL_VOCAB = "/root/reference/t3-multilingual-model/grapheme_mtl_merged_expanded_v1.json"
+
+
+@pytest.fixture(scope="module")
+def text_fx(golden_dir):
+    with open(os.path.join(golden_dir, "ref_text_fixture.json")) as f:
+        return json.load(f)
+
+
+def test_punc_norm_matches_reference(text_fx):
+    for src, want in text_fx["punc_norm"]:
+        assert punc_norm(src) == want
+
+
+def test_benchmark_job_histogram(text_fx):
+    b = text_fx["benchmark_text_1"]
+    lens = b["text_id_counts"]
+    assert b["n_chunks"] == len(lens) == 154
+    assert min(lens) == 17 and max(lens) == 484 and abs(sum(lens) / len(lens) - 151.7) < 0.1
+
+
+def test_max_tokens_rule():
+    # ceil(clamp(ceil(chars*2.2), 64, 1200) * 1.6) per prompt; batch cap = min over prompts + 16, capped
+    p_short = "[START]Hi.[STOP]"
+    p_long = "[START]" + "a" * 300 + ".[STOP]"
+    assert nonspace_chars(p_short) == 3
+    assert guard_cap(p_short) == 103            # max(64, ceil(6.6)) = 64 -> ceil(102.4)
+    assert guard_cap(p_long) == int(np.ceil(int(np.ceil(301 * 2.2)) * 1.6))
+    assert batch_max_tokens([p_short, p_long], 1000, 1000) == 103 + 16
+    assert batch_max_tokens([p_long], 1000, 400) == 400
+    assert batch_max_tokens([p_long], 50, 1000) == 50
+
+
+def test_postprocess_speech_ids():
+    from chatterbox_vllm_amd.tts import postprocess_speech_ids, STOP_OFFSET_ID
+    S = STOP_OFFSET_ID
+    assert postprocess_speech_ids([1005, 1006, 1007, 1008, S, 1009]).tolist() == [5, 6]
+    assert postprocess_speech_ids([1005, 7561, 1006, 9000]).tolist() == [6]
+    assert postprocess_speech_ids([1001, S]).tolist() == []
+    assert postprocess_speech_ids([S]).dtype == torch.int64
+    many = [1000 + (i % 6000) for i in range(500)]
+    assert len(postprocess_speech_ids(many, prompt="[START]Hi.[STOP]")) == 103          # per-prompt guard
+
+
+@pytest.mark.skipif(not os.path.isfile(REF_EN_VOCAB), reason="reference vocabulary file not present on this machine")
+def test_tokenizers_match_reference(text_fx):
+    from chatterbox_vllm_amd.tokenizer import EnTokenizer, MTLTokenizer
+    tok = EnTokenizer(REF_EN_VOCAB)
+    for s, ids in text_fx["en"]:
+        assert tok(s) == ids
+    assert tok.vocab_size == text_fx["vocab_sizes"]["en"] == 704
+    mtl = MTLTokenizer(REF_MTL_VOCAB)
+    for s, ids in text_fx["mtl_fr"]:
+        assert mtl("[fr]" + s) == ids                     # leading tag form (mtl_tts.py:423)
+        assert mtl(s, language_id="fr") == ids            # tokenization_kwargs form
+        assert ids[0] == text_fx["mtl_special_ids"]["[fr]"] and ids[1] == text_fx["mtl_special_ids"]["[START]"]
+    assert mtl("[xx]abc") != mtl("abc")                   # unknown tags stay text
+
+
+def test_korean_jamo_decomposition():
+    from chatterbox_vllm_amd.tokenizer import korean_to_jamo
+    assert korean_to_jamo("한") == "한"
+    assert korean_to_jamo("가a") == "가a"
+
+
+def test_tokenizer_lookup_fails_loudly(tmp_path, monkeypatch):
+    from chatterbox_vllm_amd.tokenizer import EnTokenizer
+    monkeypatch.chdir(tmp_path)
+    with pytest.raises(FileNotFoundError):
+        EnTokenizer.from_pretrained(str(tmp_path))
+
+
+def test_cond_encoder_matches_reference(golden_dir):
+    d = np.load(os.path.join(golden_dir, "ref_plugin_fixture.npz"))
+    w = {k[len("cond_enc."):]: v for k, v in CE.synthetic_weights(1234).items()}
+    g = torch.Generator().manual_seed(31)
+    spk = torch.randn(1, 256, generator=g)
+    prompt = torch.randn(150, 1024, generator=g) * 0.05
+    for e in (0.5, 0.8):
+        got = CE.encode(w, spk, prompt, e)
+        assert got.shape == (34, 1024)
+        assert torch.allclose(got, torch.from_numpy(d[f"condenc_out_{e}"]), atol=1e-5, rtol=1e-5)
+    assert torch.allclose(CE.emotion_row(w, 0.3), torch.from_numpy(d["condenc_emotion_row_0.3"]), atol=1e-7)
+
+
+def test_checkpoint_routing():
+    cfg = T3ModelConfig.english(n_layers=1)
+    sd = W.synthetic_state_dict(cfg)
+    assert sd["speech_head.weight"].shape == (8194, 1024) and sd["speech_head.weight"].dtype == torch.bfloat16
+    extra = dict(sd)
+    extra["text_head.weight"] = torch.zeros(704, 1024)          # skipped like t3.py:363-366
+    extra["cond_enc.spkr_enc.bias"] = torch.zeros(1024)
+    keep, skipped = W.route_checkpoint(extra.items(), cfg)
+    assert set(keep) == set(sd) and sorted(skipped) == ["cond_enc.spkr_enc.bias", "text_head.weight"]
+    with pytest.raises(KeyError):
+        W.route_checkpoint([(k, v) for k, v in sd.items() if k != "tfmr.norm.weight"], cfg)
+    bad = dict(sd)
+    bad["text_emb.weight"] = torch.zeros(700, 1024)
+    with pytest.raises(ValueError):
+        W.route_checkpoint(bad.items(), cfg)
+    full = T3ModelConfig.english()
+    assert full.backbone_params == 503378944 and full.weight_bytes_per_step == 1023539200
+    assert full.kv_bytes_per_token == 122880
+    # the tables come first in the generator walk, so they do not depend on the layer count
+    assert torch.equal(W.synthetic_state_dict(T3ModelConfig.english(n_layers=0))["speech_emb.weight"], sd["speech_emb.weight"])
+
+
+# ---- request sharding, world size 2 over gloo ------------------------------------------------
+class _FakeEngine:
+    """Deterministic stand-in: ids depend only on the request, like the real engine's greedy path."""
+
+    def generate(self, items, sps):
+        from chatterbox_vllm_amd.engine import RequestOutput, CompletionOutput
+        outs = []
+        for it, sp in zip(items, sps):
+            ids = [1000 + (7 * t + k) % 6000 for k, t in enumerate(it["prompt_token_ids"][: sp.max_tokens])]
+            outs.append(RequestOutput("x", None, it["prompt_token_ids"], [CompletionOutput(0, ids, "length")]))
+        return outs
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    from chatterbox_vllm_amd.engine import SamplingParams
+    from chatterbox_vllm_amd import sharding as S
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cfg = T3ModelConfig.english(n_layers=0)
+        sd = W.synthetic_state_dict(cfg, seed=1234 if rank == 0 else 99)        # only rank 0 holds the real values
+        got = S.broadcast_state_dict(sd, src=0)
+        want = W.synthetic_state_dict(cfg, seed=1234)
+        ok_bcast = all(torch.equal(got[k], want[k]) for k in want)
+        items = [{"prompt_token_ids": list(range(3 + i, 3 + i + 4 + (i % 5)))} for i in range(7)]
+        sps = [SamplingParams(max_tokens=3 + (i % 4)) for i in range(7)]
+        res = S.generate_sharded(_FakeEngine(), items, sps)
+        ref = [o.outputs[0].token_ids for o in _FakeEngine().generate(items, sps)]
+        ragged = S.gather_token_ids([[rank] * (rank + 1), []] if rank == 0 else [[5, 6, 7]])
+        q.put((rank, ok_bcast, res == ref, ragged, S.shard_indices(7, world, rank)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharding_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p_ in procs:
+        p_.join(60)
+        assert p_.exitcode == 0
+    for rank, ok_bcast, ok_gen, ragged, idx in res:
+        assert ok_bcast and ok_gen
+        assert ragged == [[0], [], [5, 6, 7]]
+    assert res[0][4] == [0, 2, 4, 6] and res[1][4] == [1, 3, 5]

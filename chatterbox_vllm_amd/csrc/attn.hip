@@ -137,86 +137,139 @@ int launch_attn_decode(const bf16_t* qkv, int ldq, bf16_t* out, int rows, const 
 }
 
 // ------------------------------------------------------------------------------------
-// Prefill: causal attention inside packed prompt rows, read from the step's q|k|v buffer
-// (row-major [rows, 3*H*64]).  One wave per (sequence, 64-query tile, head); a lane owns
-// one query row (q and the output row live in registers), keys are walked in order and the
-// key/value row of the step is the same for all lanes, so it arrives through the scalar
-// path.  fp32 online softmax, four keys per update.
+// Prefill: causal flash attention inside packed prompt rows, read from the step's q|k|v buffer
+// (row-major [rows, 3*H*64]).  One workgroup = (sequence, 64-query tile, head), 4 waves of 16
+// query rows each; 64-key K and V tiles are staged through LDS (K row-major, V transposed).
+//
+// Both products run on v_mfma_f32_16x16x32_bf16 with the QUERY on the lane:
+//   S^T[key][q] = K * Q^T     A = K rows from LDS, B = Q held in registers for the whole kernel;
+//                             lane (q = l&15, g = l>>4) gets keys 16t + 4g + r of sub-tile t,
+//                             so the softmax max/sum of a query is 16 registers + 2 shuffles.
+//   O^T[d][q]   = V^T * P^T   the exponentiated S^T registers are the B operand as they stand
+//                             (k-slot (g, j) <-> key 16*t(j>>2) + 4g + (j&3), the same permutation
+//                             is applied to the V^T fragment), no LDS round trip for P.
+// P is fed as hi + lo bf16 parts (two MFMAs), so the weights keep ~16 significant bits and the
+// result matches an fp32-softmax checker to bf16 rounding.  fp32 online softmax across key tiles.
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void attn_prefill_kernel(const bf16_t* __restrict__ qkv, int ldq,
-                                                          bf16_t* __restrict__ out, int ldo,
-                                                          const int32_t* __restrict__ seq_start,
-                                                          const int32_t* __restrict__ tiles, int H) {
-    const int hd = 64;
+#define PF_LD 72   // LDS row stride in elements (64 + 8 pad: 144 B keeps 16-B alignment, spreads banks)
+
+__global__ __launch_bounds__(256) void attn_prefill_kernel(const bf16_t* __restrict__ qkv, int ldq,
+                                                           bf16_t* __restrict__ out, int ldo,
+                                                           const int32_t* __restrict__ seq_start,
+                                                           const int32_t* __restrict__ tiles, int H) {
+    __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * PF_LD];
+    __shared__ __attribute__((aligned(16))) bf16_t Vt[64 * PF_LD];
+    const int hd = 64, D = H * hd;
     const int seq = tiles[2 * blockIdx.x], q0 = tiles[2 * blockIdx.x + 1];
     const int h = blockIdx.y;
     const int s0 = seq_start[seq], P = seq_start[seq + 1] - s0;
-    const int lane = threadIdx.x;
-    const int row = q0 + lane;
-    const int lrow = row < P ? row : P - 1;
-    const int D = H * hd;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, c = lane & 15;
+    const int qrow = q0 + w * 16 + c;
+    const int lq = qrow < P ? qrow : P - 1;
 
-    float q[64], o[64];
+    bf16x8 qf[2];
     {
-        const bf16_t* qp = qkv + (size_t)(s0 + lrow) * ldq + h * hd;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const u32x4 v = *reinterpret_cast<const u32x4*>(qp + j * 8);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { q[j * 8 + 2 * i] = bf_lo(v[i]) * 0.125f; q[j * 8 + 2 * i + 1] = bf_hi(v[i]) * 0.125f; }
-        }
+        const bf16_t* qp = qkv + (size_t)(s0 + lq) * ldq + h * hd + 8 * g;
+        qf[0] = *reinterpret_cast<const bf16x8*>(qp);
+        qf[1] = *reinterpret_cast<const bf16x8*>(qp + 32);
     }
-#pragma unroll
-    for (int j = 0; j < 64; ++j) o[j] = 0.f;
     float m = -1e30f, l = 0.f;
-    const int nkeys = (q0 + 64 < P) ? q0 + 64 : P;
-    const bf16_t* kbase = qkv + (size_t)s0 * ldq + D + h * hd;
-    const bf16_t* vbase = kbase + D;
-    for (int key = 0; key < nkeys; key += 4) {
-        float s[4];
+    f32x4 o[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int kk = key + u < nkeys ? key + u : nkeys - 1;
-            const unsigned* kp = reinterpret_cast<const unsigned*>(kbase + (size_t)kk * ldq);
-            float d = 0.f;
+    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int last_q = (q0 + 64 < P ? q0 + 64 : P) - 1;           // last query row of the workgroup
+    const int nkt = last_q / 64 + 1;
+    const int wave_last_q = q0 + w * 16 + 15;
+    for (int kt = 0; kt < nkt; ++kt) {
+        __syncthreads();
 #pragma unroll
-            for (int j = 0; j < 32; ++j) {
-                const unsigned wv = kp[j];
-                d = fmaf(q[2 * j], bf_lo(wv), d);
-                d = fmaf(q[2 * j + 1], bf_hi(wv), d);
-            }
-            s[u] = (key + u <= lrow && key + u < nkeys) ? d : -1e30f;
-        }
-        const float mt = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])), m);
-        const float alpha = __expf(m - mt);
-        float p[4];
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 256 * i, key = idx >> 3, ch = idx & 7;
+            int gk = kt * 64 + key;
+            gk = gk < P ? gk : P - 1;
+            const bf16_t* kp = qkv + (size_t)(s0 + gk) * ldq + D + h * hd + ch * 8;
+            const u32x4 kv = *reinterpret_cast<const u32x4*>(kp);
+            const u32x4 vv = *reinterpret_cast<const u32x4*>(kp + D);
+            *reinterpret_cast<u32x4*>(&Ks[key * PF_LD + ch * 8]) = kv;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) p[u] = s[u] > -1e29f ? __expf(s[u] - mt) : 0.f;
-        l = l * alpha + ((p[0] + p[1]) + (p[2] + p[3]));
-#pragma unroll
-        for (int j = 0; j < 64; ++j) o[j] *= alpha;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int kk = key + u < nkeys ? key + u : nkeys - 1;
-            const unsigned* vp = reinterpret_cast<const unsigned*>(vbase + (size_t)kk * ldq);
-#pragma unroll
-            for (int j = 0; j < 32; ++j) {
-                const unsigned wv = vp[j];
-                o[2 * j] = fmaf(p[u], bf_lo(wv), o[2 * j]);
-                o[2 * j + 1] = fmaf(p[u], bf_hi(wv), o[2 * j + 1]);
+            for (int e = 0; e < 4; ++e) {
+                Vt[(ch * 8 + 2 * e) * PF_LD + key] = (bf16_t)(vv[e] & 0xffffu);
+                Vt[(ch * 8 + 2 * e + 1) * PF_LD + key] = (bf16_t)(vv[e] >> 16);
             }
         }
-        m = mt;
+        __syncthreads();
+        if (kt * 64 > wave_last_q) continue;                        // wave-uniform: tile is entirely in the future
+        f32x4 st[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            st[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&Ks[(16 * t + c) * PF_LD + 32 * s + 8 * g]);
+                st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[s], st[t], 0, 0, 0);
+            }
+        }
+        float mt = -1e30f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt * 64 + 16 * t + 4 * g + r;
+                const float sv = (key <= qrow && key < P) ? st[t][r] * 0.125f : -1e30f;
+                st[t][r] = sv;
+                mt = fmaxf(mt, sv);
+            }
+        mt = fmaxf(mt, __shfl_xor(mt, 16));
+        mt = fmaxf(mt, __shfl_xor(mt, 32));
+        const float mn = fmaxf(m, mt);
+        const float alpha = __expf(m - mn);
+        float ls = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pv = st[t][r] > -1e29f ? __expf(st[t][r] - mn) : 0.f;
+                st[t][r] = pv;
+                ls += pv;
+            }
+        ls += __shfl_xor(ls, 16);
+        ls += __shfl_xor(ls, 32);
+        l = l * alpha + ls;
+        m = mn;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] *= alpha;
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            bf16x8 ph, pl;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float pv = st[2 * pr + (j >> 2)][j & 3];
+                const __bf16 hi = (__bf16)pv;
+                ph[j] = hi;
+                pl[j] = (__bf16)(pv - (float)hi);
+            }
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16_t* vp = &Vt[(16 * dt + c) * PF_LD + 4 * g];
+                const u32x2 v0 = *reinterpret_cast<const u32x2*>(vp + 16 * (2 * pr));
+                const u32x2 v1 = *reinterpret_cast<const u32x2*>(vp + 16 * (2 * pr + 1));
+                const u32x4 vcat = {v0[0], v0[1], v1[0], v1[1]};
+                const bf16x8 vf = __builtin_bit_cast(bf16x8, vcat);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, ph, o[dt], 0, 0, 0);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pl, o[dt], 0, 0, 0);
+            }
+        }
     }
-    if (row < P) {
+    if (qrow < P) {
         const float inv = 1.0f / l;
-        bf16_t* op = out + (size_t)(s0 + row) * ldo + h * hd;
+        bf16_t* op = out + (size_t)(s0 + qrow) * ldo + h * hd + 4 * g;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            u32x4 v;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = pack_bf2(o[j * 8 + 2 * i] * inv, o[j * 8 + 2 * i + 1] * inv);
-            *reinterpret_cast<u32x4*>(op + j * 8) = v;
+        for (int dt = 0; dt < 4; ++dt) {
+            const u32x2 ov = {pack_bf2(o[dt][0] * inv, o[dt][1] * inv), pack_bf2(o[dt][2] * inv, o[dt][3] * inv)};
+            *reinterpret_cast<u32x2*>(op + 16 * dt) = ov;
         }
     }
 }
@@ -224,7 +277,7 @@ __global__ __launch_bounds__(64) void attn_prefill_kernel(const bf16_t* __restri
 int launch_attn_prefill(const bf16_t* qkv, int ldq, bf16_t* out, const int32_t* seq_start_dev,
                         const int32_t* tiles_dev, int ntiles, int H, int hd, hipStream_t st) {
     T3_REQUIRE(hd == 64 && ntiles >= 1, "attn_prefill: head_dim must be 64");
-    hipLaunchKernelGGL(attn_prefill_kernel, dim3(ntiles, H), dim3(64), 0, st, qkv, ldq, out, H * hd, seq_start_dev,
+    hipLaunchKernelGGL(attn_prefill_kernel, dim3(ntiles, H), dim3(256), 0, st, qkv, ldq, out, H * hd, seq_start_dev,
                        tiles_dev, H);
     T3_HIP_CHECK(hipGetLastError());
     return 0;

@@ -34,6 +34,24 @@ extern "C" int t3_op_gemm(const void* a_dev, const void* wt_dev, void* out_dev, 
     return launch_gemm(epilogue == 0 ? EPI_STORE : EPI_RESID, g, static_cast<hipStream_t>(stream));
 }
 
+extern "C" int t3_op_gemm_slab(const void* a_dev, const void* wt_dev, float* slab_dev, int32_t M, int32_t N, int32_t K,
+                               void* stream) {
+    T3_REQUIRE(a_dev && wt_dev && slab_dev, "null argument");
+    GemmArgs g{};
+    g.A = static_cast<const bf16_t*>(a_dev); g.lda = K; g.Wt = static_cast<const bf16_t*>(wt_dev);
+    g.M = M; g.N = N; g.K = K; g.n_valid = N; g.slab = slab_dev;
+    return launch_gemm_slab(g, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int t3_op_slab_split(void) { return GEMM_SLAB_SPLIT; }
+
+extern "C" int t3_op_slab_add_rmsnorm(const float* slab_dev, int32_t nsplit, void* res_dev, const void* w_dev, void* xn_dev,
+                                      int32_t rows, int32_t d, float eps, void* stream) {
+    T3_REQUIRE(res_dev && w_dev && xn_dev, "null argument");
+    return launch_slab_add_rmsnorm(slab_dev, nsplit, static_cast<bf16_t*>(res_dev), static_cast<const bf16_t*>(w_dev),
+                                   static_cast<bf16_t*>(xn_dev), rows, d, eps, static_cast<hipStream_t>(stream));
+}
+
 extern "C" int t3_op_gemm_silu(const void* a_dev, const void* wt_dev, void* h_dev, int32_t M, int32_t F, int32_t K,
                                void* stream) {
     T3_REQUIRE(a_dev && wt_dev && h_dev, "null argument");

@@ -109,6 +109,7 @@ struct t3_engine {
     int max_rows = 0;
     int64_t cur_ctx_tokens = 0;                         // sum of context lengths of the decode rows of this step
     bf16_t *res = nullptr, *xn = nullptr, *qkv = nullptr, *att = nullptr, *hbuf = nullptr, *logits = nullptr;
+    float* slab = nullptr;                              // [GEMM_SLAB_SPLIT][n_streams][d] fp32 split-K partials (decode)
     float* cond_buf = nullptr;                          // [max_num_seqs][34][d] fp32
     uint8_t* seen = nullptr;                            // [max_num_seqs][kSeenStride]
     int32_t* last_token = nullptr;                      // [max_num_seqs]
@@ -255,7 +256,13 @@ int run_layers(t3_engine* e, int rows, const int32_t* d_pos, const int32_t* d_st
     const KvView kv = e->kvview();
     for (int li = 0; li < c.n_layers; ++li) {
         const Layer& L = e->layers[li];
-        T3_RUN(e, K_NORM, li, 4LL * rows * D, launch_add_rmsnorm(nullptr, e->res, L.ln1, e->xn, rows, D, c.rms_eps, st));
+        // decode: o_proj / down_proj leave split-K partial slabs, folded in by the next norm kernel;
+        // prefill: they add the residual in their own epilogue and the norm only normalises.
+        if (prefill)
+            T3_RUN(e, K_NORM, li, 4LL * rows * D, launch_add_rmsnorm(nullptr, e->res, L.ln1, e->xn, rows, D, c.rms_eps, st));
+        else
+            T3_RUN(e, K_NORM, li, 4LL * rows * D, launch_slab_add_rmsnorm(e->slab, li > 0 ? GEMM_SLAB_SPLIT : 0, e->res, L.ln1,
+                                                                          e->xn, rows, D, c.rms_eps, st));
         GemmArgs g{};
         g.A = e->xn; g.lda = D; g.Wt = L.wqkv; g.C = e->qkv; g.ldc = 3 * D; g.M = rows; g.N = 3 * D; g.K = D;
         g.n_valid = 3 * D; g.rope = e->rope; g.pos = d_pos; g.row_stream = d_stream; g.kv = kv; g.layer = li;
@@ -267,16 +274,29 @@ int run_layers(t3_engine* e, int rows, const int32_t* d_pos, const int32_t* d_st
         }
         GemmArgs o{};
         o.A = e->att; o.lda = D; o.Wt = L.wo; o.C = e->res; o.ldc = D; o.M = rows; o.N = D; o.K = D; o.n_valid = D;
-        T3_RUN(e, K_OPROJ, li, 2LL * D * D, launch_gemm(EPI_RESID, o, st));
-        T3_RUN(e, K_NORM, li, 4LL * rows * D, launch_add_rmsnorm(nullptr, e->res, L.ln2, e->xn, rows, D, c.rms_eps, st));
+        o.slab = e->slab;
+        if (prefill) {
+            T3_RUN(e, K_OPROJ, li, 2LL * D * D, launch_gemm(EPI_RESID, o, st));
+            T3_RUN(e, K_NORM, li, 4LL * rows * D, launch_add_rmsnorm(nullptr, e->res, L.ln2, e->xn, rows, D, c.rms_eps, st));
+        } else {
+            T3_RUN(e, K_OPROJ, li, 2LL * D * D, launch_gemm_slab(o, st));
+            T3_RUN(e, K_NORM, li, 4LL * rows * D, launch_slab_add_rmsnorm(e->slab, GEMM_SLAB_SPLIT, e->res, L.ln2, e->xn, rows, D,
+                                                                          c.rms_eps, st));
+        }
         GemmArgs u{};
         u.A = e->xn; u.lda = D; u.Wt = L.wgu; u.C = e->hbuf; u.ldc = F; u.M = rows; u.N = 2 * F; u.K = D; u.n_valid = 2 * F;
         T3_RUN(e, K_GATEUP, li, 2LL * 2 * F * D, launch_gemm(EPI_SILU, u, st));
         GemmArgs dn{};
         dn.A = e->hbuf; dn.lda = F; dn.Wt = L.wd; dn.C = e->res; dn.ldc = D; dn.M = rows; dn.N = D; dn.K = F; dn.n_valid = D;
-        T3_RUN(e, K_DOWN, li, 2LL * F * D, launch_gemm(EPI_RESID, dn, st));
+        dn.slab = e->slab;
+        if (prefill) T3_RUN(e, K_DOWN, li, 2LL * F * D, launch_gemm(EPI_RESID, dn, st));
+        else         T3_RUN(e, K_DOWN, li, 2LL * F * D, launch_gemm_slab(dn, st));
     }
-    T3_RUN(e, K_NORM, -1, 4LL * rows * D, launch_add_rmsnorm(nullptr, e->res, e->norm_w, e->xn, rows, D, c.rms_eps, st));
+    if (prefill)
+        T3_RUN(e, K_NORM, -1, 4LL * rows * D, launch_add_rmsnorm(nullptr, e->res, e->norm_w, e->xn, rows, D, c.rms_eps, st));
+    else
+        T3_RUN(e, K_NORM, -1, 4LL * rows * D, launch_slab_add_rmsnorm(e->slab, GEMM_SLAB_SPLIT, e->res, e->norm_w, e->xn, rows, D,
+                                                                      c.rms_eps, st));
     return 0;
 }
 
@@ -529,6 +549,7 @@ extern "C" int t3_engine_create(const t3_config* cfg, t3_engine** out) {
     if (dmalloc(&e->res, R * c.d_model) || dmalloc(&e->xn, R * c.d_model) || dmalloc(&e->qkv, R * 3 * c.d_model) ||
         dmalloc(&e->att, R * c.d_model) || dmalloc(&e->hbuf, R * c.d_ff) ||
         dmalloc(&e->logits, (size_t)e->n_streams * e->head_n)) return 1;
+    T3_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->slab), sizeof(float) * GEMM_SLAB_SPLIT * (size_t)e->n_streams * c.d_model));
     T3_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->cond_buf), sizeof(float) * c.max_num_seqs * kCondRows * c.d_model));
     T3_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->seen), (size_t)c.max_num_seqs * kSeenStride));
     T3_HIP_CHECK(hipMemsetAsync(e->seen, 0, (size_t)c.max_num_seqs * kSeenStride, e->stream));
@@ -643,7 +664,7 @@ extern "C" int t3_engine_destroy(t3_engine* e) {
     (void)hipFree(e->head); (void)hipFree(e->kv_pool);
     (void)hipFree(e->res); (void)hipFree(e->xn); (void)hipFree(e->qkv); (void)hipFree(e->att); (void)hipFree(e->hbuf);
     (void)hipFree(e->logits); (void)hipFree(e->cond_buf); (void)hipFree(e->seen); (void)hipFree(e->last_token);
-    (void)hipFree(e->dbg_logits);
+    (void)hipFree(e->dbg_logits); (void)hipFree(e->slab);
     e->block_table.release();
     for (auto* m : {&e->dm, &e->pm}) { m->i32.release(); m->f32.release(); m->u64.release(); }
     for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);

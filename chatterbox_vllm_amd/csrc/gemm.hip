@@ -49,6 +49,9 @@ __global__ __launch_bounds__(KW * 64) void gemm_stream_kernel(GemmArgs a) {
         half = i & 1;
         if (region < 2) { nbi[0] = region * 4 * H + head * 4 + half; nbi[1] = nbi[0] + 2; }
         else            { nbi[0] = 2 * 4 * H + head * 4 + half * 2;  nbi[1] = nbi[0] + 1; }
+    } else if constexpr (EPI == EPI_SLAB) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) nbi[nb] = b * NB + nb;
     } else {
         nbi[0] = b;
     }
@@ -59,7 +62,17 @@ __global__ __launch_bounds__(KW * 64) void gemm_stream_kernel(GemmArgs a) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[nb][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int kt0 = w * KT;
+    const int kt0 = (blockIdx.z * KW + w) * KT;       // blockIdx.z > 0 only for split-K slabs
+    // activation row addresses first: the row gather (head GEMM only) is a dependent load, and a
+    // wait for it placed after the weight loads would also wait for the whole HBM stream
+    const bf16_t* arow[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        int r = m0 + mt * 16 + (lane & 15);
+        r = r < a.M ? r : a.M - 1;
+        if constexpr (EPI == EPI_STORE_GATHER) r = a.a_rows[r];
+        arow[mt] = a.A + (size_t)r * a.lda + kt0 * 32 + 8 * (lane >> 4);
+    }
     // weight fragments: the HBM stream, issued first
     bf16x8 wf[NB][KT];
 #pragma unroll
@@ -67,15 +80,6 @@ __global__ __launch_bounds__(KW * 64) void gemm_stream_kernel(GemmArgs a) {
         const bf16x8* wp = reinterpret_cast<const bf16x8*>(a.Wt) + ((size_t)nbi[nb] * ktiles + kt0) * 64 + lane;
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) wf[nb][kt] = __builtin_nontemporal_load(wp + kt * 64);
-    }
-    // activation fragments (L2-resident)
-    const bf16_t* arow[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        int r = m0 + mt * 16 + (lane & 15);
-        r = r < a.M ? r : a.M - 1;
-        if (a.a_rows) r = a.a_rows[r];
-        arow[mt] = a.A + (size_t)r * a.lda + kt0 * 32 + 8 * (lane >> 4);
     }
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) {
@@ -108,7 +112,12 @@ __global__ __launch_bounds__(KW * 64) void gemm_stream_kernel(GemmArgs a) {
         if (r >= a.M) continue;
         const int nl = 4 * (lane >> 4);
 
-        if constexpr (EPI == EPI_STORE || EPI == EPI_RESID) {
+        if constexpr (EPI == EPI_SLAB) {
+            // fp32 partial sums of this block's K range: slab[blockIdx.z][row][col]
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+                *reinterpret_cast<f32x4*>(a.slab + ((size_t)blockIdx.z * a.M + r) * a.N + nbi[nb] * 16 + nl) = s[nb];
+        } else if constexpr (EPI == EPI_STORE || EPI == EPI_STORE_GATHER || EPI == EPI_RESID) {
             const int n = nbi[0] * 16 + nl;
             bf16_t* cp = a.C + (size_t)r * a.ldc + n;
             float v[4] = {rbf(s[0][0]), rbf(s[0][1]), rbf(s[0][2]), rbf(s[0][3])};
@@ -205,7 +214,7 @@ int launch_repack(const bf16_t* w, bf16_t* wt, int N, int K, hipStream_t st) {
 }
 
 template <int NB, int MT, int KW, int KT, int EPI>
-static int launch_one(const GemmArgs& a, int nblocks, hipStream_t st) {
+static int launch_one(const GemmArgs& a, int nblocks, hipStream_t st, int ksplit = 1) {
     constexpr size_t lds = (size_t)KW * NB * MT * 64 * sizeof(f32x4);
     static bool attr_set = false;
     if (!attr_set) {
@@ -214,17 +223,17 @@ static int launch_one(const GemmArgs& a, int nblocks, hipStream_t st) {
         attr_set = true;
     }
     const int groups = (a.M + MT * 16 - 1) / (MT * 16);
-    hipLaunchKernelGGL((gemm_stream_kernel<NB, MT, KW, KT, EPI>), dim3(nblocks, groups), dim3(KW * 64), lds, st, a);
+    hipLaunchKernelGGL((gemm_stream_kernel<NB, MT, KW, KT, EPI>), dim3(nblocks, groups, ksplit), dim3(KW * 64), lds, st, a);
     T3_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
 template <int NB, int KW, int KT, int EPI>
-static int launch_mt(const GemmArgs& a, int nblocks, hipStream_t st) {
-    if (a.M <= 16) return launch_one<NB, 1, KW, KT, EPI>(a, nblocks, st);
-    if (a.M <= 32) return launch_one<NB, 2, KW, KT, EPI>(a, nblocks, st);
-    if (a.M <= 64) return launch_one<NB, 4, KW, KT, EPI>(a, nblocks, st);
-    return launch_one<NB, 8, KW, KT, EPI>(a, nblocks, st);
+static int launch_mt(const GemmArgs& a, int nblocks, hipStream_t st, int ksplit = 1) {
+    if (a.M <= 16) return launch_one<NB, 1, KW, KT, EPI>(a, nblocks, st, ksplit);
+    if (a.M <= 32) return launch_one<NB, 2, KW, KT, EPI>(a, nblocks, st, ksplit);
+    if (a.M <= 64) return launch_one<NB, 4, KW, KT, EPI>(a, nblocks, st, ksplit);
+    return launch_one<NB, 8, KW, KT, EPI>(a, nblocks, st, ksplit);
 }
 
 int launch_gemm(int epi, const GemmArgs& a, hipStream_t st) {
@@ -234,6 +243,10 @@ int launch_gemm(int epi, const GemmArgs& a, hipStream_t st) {
     T3_REQUIRE(a.K == 1024 || a.K == 4096, "gemm: K must be 1024 or 4096");
     switch (epi) {
         case EPI_STORE:
+            if (a.a_rows) {
+                T3_REQUIRE(a.K == 1024, "gemm: row gather is built for K = 1024");
+                return launch_mt<1, 8, 4, EPI_STORE_GATHER>(a, a.N / 16, st);
+            }
             if (a.K == 1024) return launch_mt<1, 8, 4, EPI_STORE>(a, a.N / 16, st);
             return launch_mt<1, 16, 8, EPI_STORE>(a, a.N / 16, st);
         case EPI_RESID:
@@ -248,5 +261,17 @@ int launch_gemm(int epi, const GemmArgs& a, hipStream_t st) {
             return launch_mt<2, 8, 4, EPI_QKV_ROPE>(a, a.N / 32, st);
     }
     t3_set_error("gemm: unknown epilogue");
+    return 1;
+}
+
+// Split-K form for the two projections with few output columns (o_proj, down_proj: N = 1024):
+// GEMM_SLAB_SPLIT blocks share one 32-column group, each over 1/8 of K, so 256 workgroups stream
+// the weights; every block writes its fp32 partial tile to slab[split][row][col].  The partials
+// are summed in split order by the residual-add + RMSNorm kernel that follows.
+int launch_gemm_slab(const GemmArgs& a, hipStream_t st) {
+    T3_REQUIRE(a.slab != nullptr && a.M >= 1 && a.N % 32 == 0 && a.lda % 8 == 0, "gemm_slab: bad arguments");
+    if (a.K == 1024) return launch_mt<2, 4, 1, EPI_SLAB>(a, a.N / 32, st, GEMM_SLAB_SPLIT);   // 4 waves x 1 k-tile
+    if (a.K == 4096) return launch_mt<2, 8, 2, EPI_SLAB>(a, a.N / 32, st, GEMM_SLAB_SPLIT);   // 8 waves x 2 k-tiles
+    t3_set_error("gemm_slab: K must be 1024 or 4096");
     return 1;
 }

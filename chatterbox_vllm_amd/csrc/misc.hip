@@ -59,6 +59,69 @@ __global__ __launch_bounds__(128) void add_rmsnorm_kernel(const bf16_t* __restri
     }
 }
 
+// ------------------------------------------------------------------------------------
+// Decode form, d = 1024: the row (8 elements per thread) stays in registers between the
+// sum of squares and the scaling, and the split-K partial sums of the preceding projection
+// are folded in first:  res = bf16(bf16(slab[0] + slab[1] + ... ) + res)  in slab order.
+// ------------------------------------------------------------------------------------
+template <int NSPLIT>
+__global__ __launch_bounds__(128) void slab_add_rmsnorm_kernel(const float* __restrict__ slab,
+                                                               size_t slab_stride, bf16_t* __restrict__ res,
+                                                               const bf16_t* __restrict__ w, bf16_t* __restrict__ xn,
+                                                               float eps) {
+    constexpr int d = 1024;
+    __shared__ float part[2];
+    const size_t row = blockIdx.x;
+    const int tid = threadIdx.x, c = tid * 8;
+    const u32x4 rv = *reinterpret_cast<const u32x4*>(res + row * d + c);
+    const u32x4 wv = *reinterpret_cast<const u32x4*>(w + c);
+    float z[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { z[2 * i] = bf_lo(rv[i]); z[2 * i + 1] = bf_hi(rv[i]); }
+    if constexpr (NSPLIT > 0) {
+        const float* sp = slab + row * d + c;
+        f32x4 p0[NSPLIT], p1[NSPLIT];                      // all partial loads in flight at once
+#pragma unroll
+        for (int s = 0; s < NSPLIT; ++s) {
+            p0[s] = *reinterpret_cast<const f32x4*>(sp + s * slab_stride);
+            p1[s] = *reinterpret_cast<const f32x4*>(sp + s * slab_stride + 4);
+        }
+        f32x4 a0 = p0[0], a1 = p1[0];
+#pragma unroll
+        for (int s = 1; s < NSPLIT; ++s) { a0 += p0[s]; a1 += p1[s]; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { z[i] = rbf(rbf(a0[i]) + z[i]); z[4 + i] = rbf(rbf(a1[i]) + z[4 + i]); }
+        u32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = pack_bf2(z[2 * i], z[2 * i + 1]);
+        *reinterpret_cast<u32x4*>(res + row * d + c) = o;
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ss += z[i] * z[i];
+    ss = wave_sum(ss);
+    if ((tid & 63) == 0) part[tid >> 6] = ss;
+    __syncthreads();
+    const float sc = 1.0f / sqrtf((part[0] + part[1]) / (float)d + eps);
+    u32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        o[i] = pack_bf2(rbf(z[2 * i] * sc) * bf_lo(wv[i]), rbf(z[2 * i + 1] * sc) * bf_hi(wv[i]));
+    *reinterpret_cast<u32x4*>(xn + row * d + c) = o;
+}
+
+int launch_slab_add_rmsnorm(const float* slab, int nsplit, bf16_t* res, const bf16_t* w, bf16_t* xn, int rows, int d,
+                            float eps, hipStream_t st) {
+    T3_REQUIRE(rows >= 1 && d == 1024, "slab_add_rmsnorm: d must be 1024");
+    T3_REQUIRE(nsplit == 0 || (slab != nullptr && nsplit == GEMM_SLAB_SPLIT), "slab_add_rmsnorm: nsplit must be 0 or the split count");
+    if (nsplit == 0)
+        hipLaunchKernelGGL(slab_add_rmsnorm_kernel<0>, dim3(rows), dim3(128), 0, st, slab, (size_t)rows * d, res, w, xn, eps);
+    else
+        hipLaunchKernelGGL(slab_add_rmsnorm_kernel<GEMM_SLAB_SPLIT>, dim3(rows), dim3(128), 0, st, slab, (size_t)rows * d, res, w, xn, eps);
+    T3_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int launch_add_rmsnorm(const bf16_t* x, bf16_t* res, const bf16_t* w, bf16_t* xn, int rows, int d,
                        float eps, hipStream_t st) {
     T3_REQUIRE(rows >= 1 && d % 8 == 0, "add_rmsnorm: d must be a multiple of 8");
@@ -194,14 +257,42 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void sample_kernel(SampleArgs a) {
     if (ol) for (int v = tid; v < 1000; v += SAMPLE_THREADS) ol[v] = -INFINITY;
 
     MaxIdx best; best.v = -INFINITY; best.i = 0x7fffffff;
-    for (int v = tid; v < a.vocab; v += SAMPLE_THREADS) {
-        const float c = bf2f(lc[v]);
-        float l = c;
-        if (lu) l = rbf(c + rbf(a.cfg_scale * rbf(c - bf2f(lu[v]))));
-        if (pen != 1.0f && seen[v + 1000]) l = l > 0.f ? l / pen : l * pen;
-        sl[v] = l;
-        if (ol) ol[v + 1000] = l;
-        if (l > best.v) { best.v = l; best.i = v; }
+    // 8 consecutive columns per thread and pass: 16-byte logit loads, one 8-byte load of seen flags
+    // (rows are 16-byte aligned: ldl % 8 == 0, seen stride % 8 == 0, and 1000 % 8 == 0)
+    for (int v0 = tid * 8; v0 < a.vocab; v0 += SAMPLE_THREADS * 8) {
+        float c[8], u[8];
+        unsigned char sf[8];
+        if (v0 + 8 <= a.vocab) {
+            const u32x4 cv = *reinterpret_cast<const u32x4*>(lc + v0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { c[2 * k] = bf_lo(cv[k]); c[2 * k + 1] = bf_hi(cv[k]); }
+            if (lu) {
+                const u32x4 uv = *reinterpret_cast<const u32x4*>(lu + v0);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { u[2 * k] = bf_lo(uv[k]); u[2 * k + 1] = bf_hi(uv[k]); }
+            }
+            const u32x2 sv = *reinterpret_cast<const u32x2*>(seen + v0 + 1000);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) sf[k] = (unsigned char)((sv[k >> 2] >> (8 * (k & 3))) & 0xff);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int v = v0 + k < a.vocab ? v0 + k : a.vocab - 1;
+                c[k] = bf2f(lc[v]); u[k] = lu ? bf2f(lu[v]) : 0.f; sf[k] = seen[v + 1000];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int v = v0 + k;
+            if (v < a.vocab) {
+                float l = c[k];
+                if (lu) l = rbf(c[k] + rbf(a.cfg_scale * rbf(c[k] - u[k])));
+                if (pen != 1.0f && sf[k]) l = l > 0.f ? l / pen : l * pen;
+                sl[v] = l;
+                if (ol) ol[v + 1000] = l;
+                if (l > best.v) { best.v = l; best.i = v; }
+            }
+        }
     }
     best = block_argmax(best, shm);
     int tok = best.i;
@@ -257,7 +348,8 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void sample_kernel(SampleArgs a) {
 
 int launch_sample(const SampleArgs& a, hipStream_t st) {
     T3_REQUIRE(a.n >= 1 && a.vocab <= SAMPLE_MAX_VOCAB, "sample: vocab too large");
-    T3_REQUIRE(a.seen_stride >= a.vocab + 1000, "sample: seen rows too short");
+    T3_REQUIRE(a.seen_stride >= a.vocab + 1000 && a.seen_stride % 8 == 0, "sample: seen rows too short or unaligned");
+    T3_REQUIRE(a.ldl % 8 == 0, "sample: logits row stride must be a multiple of 8");
     hipLaunchKernelGGL(sample_kernel, dim3(a.n), dim3(SAMPLE_THREADS), 0, st, a);
     T3_HIP_CHECK(hipGetLastError());
     return 0;

@@ -53,7 +53,8 @@ struct KvView {
 };
 
 // ---- launchers (all asynchronous on `st`) -------------------------------------------
-enum GemmEpilogue { EPI_STORE = 0, EPI_RESID = 1, EPI_SILU = 2, EPI_QKV_ROPE = 3 };
+enum GemmEpilogue { EPI_STORE = 0, EPI_RESID = 1, EPI_SILU = 2, EPI_QKV_ROPE = 3, EPI_SLAB = 4, EPI_STORE_GATHER = 5 };
+#define GEMM_SLAB_SPLIT 8          // K is cut into 8 block-level ranges in the split-K (slab) form
 
 struct GemmArgs {
     const bf16_t* A; int lda;          // activations [M, K]
@@ -65,8 +66,15 @@ struct GemmArgs {
     // EPI_QKV_ROPE
     const bf16_t* rope; const int32_t* pos; const int32_t* row_stream;
     KvView kv; int layer;
+    // EPI_SLAB
+    float* slab;                       // [GEMM_SLAB_SPLIT][M][N] fp32 partial sums
 };
 int launch_gemm(int epi, const GemmArgs& a, hipStream_t st);
+int launch_gemm_slab(const GemmArgs& a, hipStream_t st);
+// res = bf16(bf16(sum_s slab[s]) + res) when slab != nullptr (nsplit slabs of [rows, d] fp32);
+// xn = rmsnorm(res) * w.  One pass, the row stays in registers.
+int launch_slab_add_rmsnorm(const float* slab, int nsplit, bf16_t* res, const bf16_t* w, bf16_t* xn, int rows, int d,
+                            float eps, hipStream_t st);
 int launch_repack(const bf16_t* w, bf16_t* wt, int N, int K, hipStream_t st);
 int launch_add_rmsnorm(const bf16_t* x, bf16_t* res, const bf16_t* w, bf16_t* xn, int rows, int d,
                        float eps, hipStream_t st);

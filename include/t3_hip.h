@@ -133,6 +133,14 @@ int t3_op_add_rmsnorm(const void* x_dev, void* res_dev, const void* w_dev, void*
  * 1: out = bf16(bf16(acc) + out) (residual add in place). */
 int t3_op_gemm(const void* a_dev, const void* wt_dev, void* out_dev, int32_t M, int32_t N, int32_t K,
                int32_t ldc, int32_t epilogue, void* stream);
+/* Split-K form used by the decode path for o_proj / down_proj (N = 1024): K is cut into
+ * t3_op_slab_split() ranges, slab[s][M][N] (fp32) receives the partial sums of range s. */
+int t3_op_gemm_slab(const void* a_dev, const void* wt_dev, float* slab_dev, int32_t M, int32_t N, int32_t K, void* stream);
+int t3_op_slab_split(void);
+/* res = bf16(bf16(slab[0] + ... + slab[nsplit-1]) + res) (skipped when nsplit == 0), then
+ * xn = rmsnorm(res) * w; d must be 1024.  The decode-path partner of t3_op_gemm_slab. */
+int t3_op_slab_add_rmsnorm(const float* slab_dev, int32_t nsplit, void* res_dev, const void* w_dev, void* xn_dev,
+                           int32_t rows, int32_t d, float eps, void* stream);
 /* h[M,F] = bf16(bf16(silu(g)) * u) with [g|u] = bf16(A[M,K] @ Wgu[2F,K]^T)  (LlamaMLP). */
 int t3_op_gemm_silu(const void* a_dev, const void* wt_dev, void* h_dev, int32_t M, int32_t F, int32_t K,
                     void* stream);

@@ -289,3 +289,45 @@ def test_sampler_cfg_penalty_argmax_is_exact(capi):
         assert int(toks[i]) == T3Oracle.greedy(ref)
         assert int(seen_d[i, int(toks[i])]) == 1              # chosen column joins the seen set
     assert int(toks[0]) == 1077
+
+
+@pytest.mark.parametrize("M", [1, 30, 64, 100])
+@pytest.mark.parametrize("K", [1024, 4096])
+def test_split_k_slabs_then_residual_norm(capi, M, K):
+    """Decode-path pair: t3_op_gemm_slab leaves fp32 partial sums, t3_op_slab_add_rmsnorm folds them
+    into the residual stream and normalises.  Equals gemm + residual add + rmsnorm of the contract."""
+    N = 1024
+    S = capi.t3_op_slab_split()
+    a = _rand((M, K), 70).to(DEV)
+    w = _rand((N, K), 71, 0.02).to(DEV)
+    wt = repack(capi, w)
+    slab = torch.full((S, M, N), float("nan"), device=DEV)
+    call(capi, "t3_op_gemm_slab", p(a), p(wt), p(slab), M, N, K, None)
+    torch.cuda.synchronize()
+    ref = a.float() @ w.float().T
+    assert torch.isfinite(slab).all()
+    assert torch.allclose(slab.sum(0), ref, rtol=1e-4, atol=1e-4)
+    res = _rand((M, N), 72).to(DEV)
+    res0 = res.clone()
+    g = (1 + 0.1 * _rand((N,), 73).float()).to(torch.bfloat16).to(DEV)
+    xn = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    call(capi, "t3_op_slab_add_rmsnorm", p(slab), S, p(res), p(g), p(xn), M, N, C.c_float(1e-5), None)
+    torch.cuda.synchronize()
+    z = r16(r16(ref) + res0.float())
+    assert_bf16_close(res, r16(ref) + res0.float(), mag=torch.maximum(ref.abs(), res0.float().abs()), ulps=1.5,
+                      what="slab residual")
+    zz = res.float()                                        # normalise what the kernel actually stored
+    assert_bf16_close(xn, r16(zz * torch.rsqrt((zz * zz).mean(-1, keepdim=True) + 1e-5)) * g.float(), ulps=2,
+                      what="slab rmsnorm")
+    # rows do not depend on the batch
+    if M > 1:
+        slab1 = torch.zeros(S, 1, N, device=DEV)
+        a1 = a[:1].contiguous()
+        call(capi, "t3_op_gemm_slab", p(a1), p(wt), p(slab1), 1, N, K, None)
+        torch.cuda.synchronize()
+        assert torch.equal(slab1[:, 0], slab[:, 0])
+    # nsplit == 0 leaves the residual alone
+    res2 = res0.clone()
+    call(capi, "t3_op_slab_add_rmsnorm", None, 0, p(res2), p(g), p(xn), M, N, C.c_float(1e-5), None)
+    torch.cuda.synchronize()
+    assert torch.equal(res2, res0)

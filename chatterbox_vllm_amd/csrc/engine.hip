@@ -8,9 +8,18 @@
 //
 // Step = (a) admit waiting requests while a slot, the page reservation and the prompt-row
 // budget allow, (b) prefill the admitted prompts whole and sample their first token,
-// (c) decode one token for every request that was already running, (d) one host sync, stop
-// checks, slot/page release.  Sampled ids stay on the device (last_token[slot]) and feed the
-// next step's embedding gather; the host only reads them for stop detection and output.
+// (c) decode one token for every request that was already running, (d) stop checks and
+// slot/page release.  Sampled ids stay on the device (last_token[slot]) and feed the next
+// step's embedding gather; the host only reads them for stop detection and output.
+//
+// Steps are pipelined one deep: a call to t3_engine_step launches step k+1 and only then waits
+// for step k and reports its tokens, so the GPU always has the next step queued while the host
+// does its bookkeeping.  Step k+1 is planned before step k's tokens are known: length limits are
+// known in advance, a stop token is not, so a request that stops in step k still rides along in
+// step k+1; that one speculative row is discarded and the request's slot and pages are only
+// released once the step that carried it has completed.  Host-side metadata is double-buffered
+// by step parity.  The measuring/debugging modes (timing, kernel timing, logit taps,
+// T3_DEBUG_SYNC, T3_ASYNC=0) run each step to completion inside the call instead.
 //
 // KV pages hold 64 positions of one stream for all layers.  Pages are handed out lazily as a
 // stream grows; admission reserves the worst case (prompt + max_tokens, capped by
@@ -49,7 +58,10 @@ struct Request {
     t3_sampling sp{};
     int slot = -1;
     int prompt_len = 0;               // 34 + T + 1
-    int n_out = 0;
+    int n_out = 0;                    // tokens reported to the caller
+    int n_launched = 0;               // tokens whose computation has been enqueued (>= n_out)
+    int limit = 0;                    // tokens this request may produce before it ends on length
+    bool zombie = false;              // stopped or aborted while a launched step still carries it
     int reserve_pages = 0;            // worst-case pages per stream
     int have_pages = 0;               // pages allocated per stream
     bool aborted = false;
@@ -105,11 +117,14 @@ struct t3_engine {
     Pinned<int32_t> block_table;                        // [n_streams][max_pages]
     bool block_table_dirty = true;
 
-    // activations
+    // activations (shared by prefill and decode: steps execute in stream order)
+    struct Bufs {
+        bf16_t *res = nullptr, *xn = nullptr, *qkv = nullptr, *att = nullptr, *hbuf = nullptr, *logits = nullptr;
+        float* slab = nullptr;                          // [GEMM_SLAB_SPLIT][rows][d] fp32 split-K partials (decode)
+    } bufs;
+    Bufs* b = &bufs;
     int max_rows = 0;
-    int64_t cur_ctx_tokens = 0;                         // sum of context lengths of the decode rows of this step
-    bf16_t *res = nullptr, *xn = nullptr, *qkv = nullptr, *att = nullptr, *hbuf = nullptr, *logits = nullptr;
-    float* slab = nullptr;                              // [GEMM_SLAB_SPLIT][n_streams][d] fp32 split-K partials (decode)
+    int64_t cur_ctx_tokens = 0;                         // sum of context lengths of the decode rows being enqueued
     float* cond_buf = nullptr;                          // [max_num_seqs][34][d] fp32
     uint8_t* seen = nullptr;                            // [max_num_seqs][kSeenStride]
     int32_t* last_token = nullptr;                      // [max_num_seqs]
@@ -124,7 +139,18 @@ struct t3_engine {
         float *rep, *temp, *top_p, *min_p;
         uint64_t* seed;
         size_t rows_cap = 0, req_cap = 0;
-    } dm, pm;                                            // decode / prefill
+    } dm[2], pm[2];                                      // decode / prefill, by step parity
+    int32_t* bt_stage[2] = {nullptr, nullptr};          // pinned snapshots of the block table, by step parity
+
+    // the step that has been launched but not yet reported
+    struct InFlight {
+        bool valid = false;
+        int parity = 0;
+        std::vector<Request*> admitted, running;
+    } inflight;
+    int parity = 0;
+    hipEvent_t step_done[2] = {nullptr, nullptr};
+    bool async_steps = true;
 
     std::deque<std::unique_ptr<Request>> waiting;
     std::vector<std::unique_ptr<Request>> slots;
@@ -247,7 +273,7 @@ int ktime_collect(t3_engine* e) {
 
 int dmalloc(bf16_t** p, size_t elems) { T3_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(p), elems * sizeof(bf16_t))); return 0; }
 
-// ---- the layer stack over `rows` rows whose embeddings are already in e->res ----------
+// ---- the layer stack over `rows` rows whose embeddings are already in e->b->res ----------
 int run_layers(t3_engine* e, int rows, const int32_t* d_pos, const int32_t* d_stream, const int32_t* d_ctx,
                bool prefill, const int32_t* d_seq_start, const int32_t* d_tiles, int ntiles) {
     const t3_config& c = e->cfg;
@@ -259,43 +285,43 @@ int run_layers(t3_engine* e, int rows, const int32_t* d_pos, const int32_t* d_st
         // decode: o_proj / down_proj leave split-K partial slabs, folded in by the next norm kernel;
         // prefill: they add the residual in their own epilogue and the norm only normalises.
         if (prefill)
-            T3_RUN(e, K_NORM, li, 4LL * rows * D, launch_add_rmsnorm(nullptr, e->res, L.ln1, e->xn, rows, D, c.rms_eps, st));
+            T3_RUN(e, K_NORM, li, 4LL * rows * D, launch_add_rmsnorm(nullptr, e->b->res, L.ln1, e->b->xn, rows, D, c.rms_eps, st));
         else
-            T3_RUN(e, K_NORM, li, 4LL * rows * D, launch_slab_add_rmsnorm(e->slab, li > 0 ? GEMM_SLAB_SPLIT : 0, e->res, L.ln1,
-                                                                          e->xn, rows, D, c.rms_eps, st));
+            T3_RUN(e, K_NORM, li, 4LL * rows * D, launch_slab_add_rmsnorm(e->b->slab, li > 0 ? GEMM_SLAB_SPLIT : 0, e->b->res, L.ln1,
+                                                                          e->b->xn, rows, D, c.rms_eps, st));
         GemmArgs g{};
-        g.A = e->xn; g.lda = D; g.Wt = L.wqkv; g.C = e->qkv; g.ldc = 3 * D; g.M = rows; g.N = 3 * D; g.K = D;
+        g.A = e->b->xn; g.lda = D; g.Wt = L.wqkv; g.C = e->b->qkv; g.ldc = 3 * D; g.M = rows; g.N = 3 * D; g.K = D;
         g.n_valid = 3 * D; g.rope = e->rope; g.pos = d_pos; g.row_stream = d_stream; g.kv = kv; g.layer = li;
         T3_RUN(e, K_QKV, li, 2LL * 3 * D * D, launch_gemm(EPI_QKV_ROPE, g, st));
         if (prefill) {
-            T3_RUN(e, K_ATTN_PREFILL, li, 2LL * rows * 4 * D, launch_attn_prefill(e->qkv, 3 * D, e->att, d_seq_start, d_tiles, ntiles, H, hd, st));
+            T3_RUN(e, K_ATTN_PREFILL, li, 2LL * rows * 4 * D, launch_attn_prefill(e->b->qkv, 3 * D, e->b->att, d_seq_start, d_tiles, ntiles, H, hd, st));
         } else {
-            T3_RUN(e, K_ATTN_DECODE, li, e->cur_ctx_tokens * 4LL * D, launch_attn_decode(e->qkv, 3 * D, e->att, rows, d_stream, d_ctx, kv, li, st));
+            T3_RUN(e, K_ATTN_DECODE, li, e->cur_ctx_tokens * 4LL * D, launch_attn_decode(e->b->qkv, 3 * D, e->b->att, rows, d_stream, d_ctx, kv, li, st));
         }
         GemmArgs o{};
-        o.A = e->att; o.lda = D; o.Wt = L.wo; o.C = e->res; o.ldc = D; o.M = rows; o.N = D; o.K = D; o.n_valid = D;
-        o.slab = e->slab;
+        o.A = e->b->att; o.lda = D; o.Wt = L.wo; o.C = e->b->res; o.ldc = D; o.M = rows; o.N = D; o.K = D; o.n_valid = D;
+        o.slab = e->b->slab;
         if (prefill) {
             T3_RUN(e, K_OPROJ, li, 2LL * D * D, launch_gemm(EPI_RESID, o, st));
-            T3_RUN(e, K_NORM, li, 4LL * rows * D, launch_add_rmsnorm(nullptr, e->res, L.ln2, e->xn, rows, D, c.rms_eps, st));
+            T3_RUN(e, K_NORM, li, 4LL * rows * D, launch_add_rmsnorm(nullptr, e->b->res, L.ln2, e->b->xn, rows, D, c.rms_eps, st));
         } else {
             T3_RUN(e, K_OPROJ, li, 2LL * D * D, launch_gemm_slab(o, st));
-            T3_RUN(e, K_NORM, li, 4LL * rows * D, launch_slab_add_rmsnorm(e->slab, GEMM_SLAB_SPLIT, e->res, L.ln2, e->xn, rows, D,
+            T3_RUN(e, K_NORM, li, 4LL * rows * D, launch_slab_add_rmsnorm(e->b->slab, GEMM_SLAB_SPLIT, e->b->res, L.ln2, e->b->xn, rows, D,
                                                                           c.rms_eps, st));
         }
         GemmArgs u{};
-        u.A = e->xn; u.lda = D; u.Wt = L.wgu; u.C = e->hbuf; u.ldc = F; u.M = rows; u.N = 2 * F; u.K = D; u.n_valid = 2 * F;
+        u.A = e->b->xn; u.lda = D; u.Wt = L.wgu; u.C = e->b->hbuf; u.ldc = F; u.M = rows; u.N = 2 * F; u.K = D; u.n_valid = 2 * F;
         T3_RUN(e, K_GATEUP, li, 2LL * 2 * F * D, launch_gemm(EPI_SILU, u, st));
         GemmArgs dn{};
-        dn.A = e->hbuf; dn.lda = F; dn.Wt = L.wd; dn.C = e->res; dn.ldc = D; dn.M = rows; dn.N = D; dn.K = F; dn.n_valid = D;
-        dn.slab = e->slab;
+        dn.A = e->b->hbuf; dn.lda = F; dn.Wt = L.wd; dn.C = e->b->res; dn.ldc = D; dn.M = rows; dn.N = D; dn.K = F; dn.n_valid = D;
+        dn.slab = e->b->slab;
         if (prefill) T3_RUN(e, K_DOWN, li, 2LL * F * D, launch_gemm(EPI_RESID, dn, st));
         else         T3_RUN(e, K_DOWN, li, 2LL * F * D, launch_gemm_slab(dn, st));
     }
     if (prefill)
-        T3_RUN(e, K_NORM, -1, 4LL * rows * D, launch_add_rmsnorm(nullptr, e->res, e->norm_w, e->xn, rows, D, c.rms_eps, st));
+        T3_RUN(e, K_NORM, -1, 4LL * rows * D, launch_add_rmsnorm(nullptr, e->b->res, e->norm_w, e->b->xn, rows, D, c.rms_eps, st));
     else
-        T3_RUN(e, K_NORM, -1, 4LL * rows * D, launch_slab_add_rmsnorm(e->slab, GEMM_SLAB_SPLIT, e->res, e->norm_w, e->xn, rows, D,
+        T3_RUN(e, K_NORM, -1, 4LL * rows * D, launch_slab_add_rmsnorm(e->b->slab, GEMM_SLAB_SPLIT, e->b->res, e->norm_w, e->b->xn, rows, D,
                                                                       c.rms_eps, st));
     return 0;
 }
@@ -303,11 +329,11 @@ int run_layers(t3_engine* e, int rows, const int32_t* d_pos, const int32_t* d_st
 int run_head_and_sample(t3_engine* e, t3_engine::Meta& m, int head_rows, const int32_t* d_a_rows, int n_req) {
     const t3_config& c = e->cfg;
     GemmArgs g{};
-    g.A = e->xn; g.lda = c.d_model; g.a_rows = d_a_rows; g.Wt = e->head; g.C = e->logits; g.ldc = e->head_n;
+    g.A = e->b->xn; g.lda = c.d_model; g.a_rows = d_a_rows; g.Wt = e->head; g.C = e->b->logits; g.ldc = e->head_n;
     g.M = head_rows; g.N = e->head_n; g.K = c.d_model; g.n_valid = e->head_n;
     T3_RUN(e, K_HEAD, -1, 2LL * e->head_n * c.d_model, launch_gemm(EPI_STORE, g, e->stream));
     SampleArgs s{};
-    s.logits = e->logits; s.ldl = e->head_n; s.vocab = c.speech_vocab;
+    s.logits = e->b->logits; s.ldl = e->head_n; s.vocab = c.speech_vocab;
     s.row_c = dev_of(m.i32, m.row_c); s.row_u = dev_of(m.i32, m.row_u); s.slot = dev_of(m.i32, m.slot);
     s.n = n_req; s.cfg_scale = c.cfg_scale;
     s.rep_penalty = dev_of(m.f32, m.rep); s.temperature = dev_of(m.f32, m.temp);
@@ -322,7 +348,7 @@ int run_head_and_sample(t3_engine* e, t3_engine::Meta& m, int head_rows, const i
 
 void fill_sampling(t3_engine::Meta& m, int i, const Request& r) {
     m.slot[i] = r.slot;
-    m.step[i] = r.n_out;
+    m.step[i] = r.n_launched;                          // index of the token being sampled
     m.rep[i] = r.sp.repetition_penalty;
     m.temp[i] = r.sp.temperature;
     m.top_p[i] = r.sp.top_p;
@@ -354,9 +380,13 @@ void release_request(t3_engine* e, Request& r) {
     e->reserved_unallocated -= (int64_t)(r.reserve_pages - r.have_pages) * e->nstreams_per_req;
 }
 
+// The host table keeps changing while earlier copies may still be queued, so each step uploads
+// from its own parity's snapshot.
 int sync_block_table(t3_engine* e) {
     if (!e->block_table_dirty) return 0;
-    T3_HIP_CHECK(hipMemcpyAsync(e->block_table.d, e->block_table.h, sizeof(int32_t) * e->block_table.n,
+    int32_t* stage = e->bt_stage[e->parity];
+    std::memcpy(stage, e->block_table.h, sizeof(int32_t) * e->block_table.n);
+    T3_HIP_CHECK(hipMemcpyAsync(e->block_table.d, stage, sizeof(int32_t) * e->block_table.n,
                                 hipMemcpyHostToDevice, e->stream));
     e->block_table_dirty = false;
     return 0;
@@ -365,7 +395,7 @@ int sync_block_table(t3_engine* e) {
 // ---- prefill of newly admitted requests ------------------------------------------------
 int run_prefill(t3_engine* e, const std::vector<Request*>& reqs) {
     const t3_config& c = e->cfg;
-    t3_engine::Meta& m = e->pm;
+    t3_engine::Meta& m = e->pm[e->parity];
     const int S = e->nstreams_per_req, n = (int)reqs.size();
     int row = 0, nseq = 0, ntiles = 0, pid = 0;
     for (int i = 0; i < n; ++i) {
@@ -417,7 +447,7 @@ int run_prefill(t3_engine* e, const std::vector<Request*>& reqs) {
         pid += len;
     }
     EmbedArgs ea{};
-    ea.out = e->res; ea.d = c.d_model; ea.rows = rows;
+    ea.out = e->b->res; ea.d = c.d_model; ea.rows = rows;
     ea.kind = dev_of(m.i32, m.ekind); ea.idx = dev_of(m.i32, m.eidx); ea.aux = dev_of(m.i32, m.eaux);
     ea.cond = e->cond_buf; ea.text_emb = e->text_emb; ea.text_pos = e->text_pos;
     ea.speech_emb = e->speech_emb; ea.speech_pos = e->speech_pos; ea.last_token = e->last_token; ea.sos_id = kSOS;
@@ -431,12 +461,11 @@ int run_prefill(t3_engine* e, const std::vector<Request*>& reqs) {
 }
 
 // ---- one decode token for the running requests -------------------------------------------
-int enqueue_decode(t3_engine* e, int B) {
+int enqueue_decode(t3_engine* e, t3_engine::Meta& m, int B) {
     const t3_config& c = e->cfg;
-    t3_engine::Meta& m = e->dm;
     const int rows = B * e->nstreams_per_req;
     EmbedArgs ea{};
-    ea.out = e->res; ea.d = c.d_model; ea.rows = rows;
+    ea.out = e->b->res; ea.d = c.d_model; ea.rows = rows;
     ea.kind = dev_of(m.i32, m.ekind); ea.idx = dev_of(m.i32, m.eidx); ea.aux = dev_of(m.i32, m.eaux);
     ea.cond = e->cond_buf; ea.text_emb = e->text_emb; ea.text_pos = e->text_pos;
     ea.speech_emb = e->speech_emb; ea.speech_pos = e->speech_pos; ea.last_token = e->last_token; ea.sos_id = kSOS;
@@ -447,12 +476,12 @@ int enqueue_decode(t3_engine* e, int B) {
 }
 
 int run_decode(t3_engine* e, const std::vector<Request*>& reqs) {
-    t3_engine::Meta& m = e->dm;
     const int S = e->nstreams_per_req, B = (int)reqs.size();
+    t3_engine::Meta& m = e->dm[e->parity];
     int64_t ctx_total = 0;
     for (int i = 0; i < B; ++i) {
         Request& r = *reqs[i];
-        const int pos = r.prompt_len + r.n_out - 1;          // position of the token fed this step
+        const int pos = r.prompt_len + r.n_launched - 1;      // position of the token fed this step
         if (grow_pages(e, r, pos + 1)) return 1;
         for (int u = 0; u < S; ++u) {
             const int row = u * B + i;
@@ -466,28 +495,29 @@ int run_decode(t3_engine* e, const std::vector<Request*>& reqs) {
         m.row_u[i] = S == 2 ? B + i : -1;
         fill_sampling(m, i, r);
     }
+    e->cur_ctx_tokens = ctx_total;
     if (sync_block_table(e)) return 1;
     if (upload(e, m)) return 1;
-    e->cur_ctx_tokens = ctx_total;
     e->kphase = 0;
-    const bool graphs = e->cfg.use_graphs && !e->keep_logits && !e->debug_sync && !e->ktiming;
-    if (graphs && e->rows_seen[B]++ >= 1) {
-        auto it = e->graphs.find(B);
+    const bool plain = !e->keep_logits && !e->debug_sync && !e->ktiming;   // those modes need eager launches
+    const int key = B * 2 + e->parity;                                     // graphs bake in the metadata pointers
+    if (e->cfg.use_graphs && plain && e->rows_seen[key]++ >= 1) {
+        auto it = e->graphs.find(key);
         if (it == e->graphs.end()) {
             hipGraph_t graph = nullptr;
             T3_HIP_CHECK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
-            const int rc = enqueue_decode(e, B);
+            const int rc = enqueue_decode(e, m, B);
             const hipError_t ce = hipStreamEndCapture(e->stream, &graph);
             if (rc) return 1;
             T3_HIP_CHECK(ce);
             hipGraphExec_t exec = nullptr;
             T3_HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
             T3_HIP_CHECK(hipGraphDestroy(graph));
-            it = e->graphs.emplace(B, exec).first;
+            it = e->graphs.emplace(key, exec).first;
         }
         T3_HIP_CHECK(hipGraphLaunch(it->second, e->stream));
     } else {
-        if (enqueue_decode(e, B)) return 1;
+        if (enqueue_decode(e, m, B)) return 1;
     }
     e->stats.decode_requests = B;
     e->stats.decode_rows = B * S;
@@ -545,11 +575,20 @@ extern "C" int t3_engine_create(const t3_config* cfg, t3_engine** out) {
     // activations
     const int prefill_rows = c.max_prefill_rows * e->nstreams_per_req;
     e->max_rows = std::max(prefill_rows, e->n_streams);
-    const size_t R = e->max_rows;
-    if (dmalloc(&e->res, R * c.d_model) || dmalloc(&e->xn, R * c.d_model) || dmalloc(&e->qkv, R * 3 * c.d_model) ||
-        dmalloc(&e->att, R * c.d_model) || dmalloc(&e->hbuf, R * c.d_ff) ||
-        dmalloc(&e->logits, (size_t)e->n_streams * e->head_n)) return 1;
-    T3_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->slab), sizeof(float) * GEMM_SLAB_SPLIT * (size_t)e->n_streams * c.d_model));
+    {
+        const size_t R = (size_t)e->max_rows, RD = (size_t)e->n_streams;
+        t3_engine::Bufs& b = e->bufs;
+        if (dmalloc(&b.res, R * c.d_model) || dmalloc(&b.xn, R * c.d_model) || dmalloc(&b.qkv, R * 3 * c.d_model) ||
+            dmalloc(&b.att, R * c.d_model) || dmalloc(&b.hbuf, R * c.d_ff) || dmalloc(&b.logits, RD * e->head_n)) return 1;
+        T3_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&b.slab), sizeof(float) * GEMM_SLAB_SPLIT * RD * c.d_model));
+    }
+    e->b = &e->bufs;
+    if (const char* ug = getenv("T3_USE_GRAPHS")) e->cfg.use_graphs = atoi(ug) != 0;
+    if (const char* as = getenv("T3_ASYNC")) e->async_steps = atoi(as) != 0;
+    for (int q = 0; q < 2; ++q) {
+        T3_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&e->bt_stage[q]), sizeof(int32_t) * e->block_table.n));
+        T3_HIP_CHECK(hipEventCreateWithFlags(&e->step_done[q], hipEventDisableTiming));
+    }
     T3_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->cond_buf), sizeof(float) * c.max_num_seqs * kCondRows * c.d_model));
     T3_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->seen), (size_t)c.max_num_seqs * kSeenStride));
     T3_HIP_CHECK(hipMemsetAsync(e->seen, 0, (size_t)c.max_num_seqs * kSeenStride, e->stream));
@@ -557,8 +596,10 @@ extern "C" int t3_engine_create(const t3_config* cfg, t3_engine** out) {
     T3_HIP_CHECK(hipMemsetAsync(e->last_token, 0, sizeof(int32_t) * c.max_num_seqs, e->stream));
     T3_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->dbg_logits),
                            sizeof(float) * c.max_num_seqs * (size_t)(c.speech_vocab + kOffset)));
-    if (meta_alloc(e->dm, e->n_streams, c.max_num_seqs, 16)) return 1;
-    if (meta_alloc(e->pm, prefill_rows, c.max_num_seqs, (size_t)c.max_prefill_rows + (size_t)c.max_num_seqs * 64)) return 1;
+    for (int q = 0; q < 2; ++q) {
+        if (meta_alloc(e->dm[q], e->n_streams, c.max_num_seqs, 16)) return 1;
+        if (meta_alloc(e->pm[q], prefill_rows, c.max_num_seqs, (size_t)c.max_prefill_rows + (size_t)c.max_num_seqs * 64)) return 1;
+    }
     for (auto& ev : e->ev) T3_HIP_CHECK(hipEventCreate(&ev));
     T3_HIP_CHECK(hipStreamSynchronize(e->stream));
     *out = e.release();
@@ -662,11 +703,18 @@ extern "C" int t3_engine_destroy(t3_engine* e) {
     for (auto& kv : e->raw) (void)hipFree(kv.second.p);
     for (auto& L : e->layers) { (void)hipFree(L.wqkv); (void)hipFree(L.wo); (void)hipFree(L.wgu); (void)hipFree(L.wd); }
     (void)hipFree(e->head); (void)hipFree(e->kv_pool);
-    (void)hipFree(e->res); (void)hipFree(e->xn); (void)hipFree(e->qkv); (void)hipFree(e->att); (void)hipFree(e->hbuf);
-    (void)hipFree(e->logits); (void)hipFree(e->cond_buf); (void)hipFree(e->seen); (void)hipFree(e->last_token);
-    (void)hipFree(e->dbg_logits); (void)hipFree(e->slab);
+    {
+        auto& b = e->bufs;
+        (void)hipFree(b.res); (void)hipFree(b.xn); (void)hipFree(b.qkv); (void)hipFree(b.att); (void)hipFree(b.hbuf);
+        (void)hipFree(b.logits); (void)hipFree(b.slab);
+    }
+    (void)hipFree(e->cond_buf); (void)hipFree(e->seen); (void)hipFree(e->last_token); (void)hipFree(e->dbg_logits);
+    for (int q = 0; q < 2; ++q) {
+        if (e->bt_stage[q]) (void)hipHostFree(e->bt_stage[q]);
+        if (e->step_done[q]) (void)hipEventDestroy(e->step_done[q]);
+    }
     e->block_table.release();
-    for (auto* m : {&e->dm, &e->pm}) { m->i32.release(); m->f32.release(); m->u64.release(); }
+    for (auto* m : {&e->dm[0], &e->dm[1], &e->pm[0], &e->pm[1]}) { m->i32.release(); m->f32.release(); m->u64.release(); }
     for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
     for (auto& ev : e->kpool) (void)hipEventDestroy(ev);
     (void)hipStreamDestroy(e->stream);
@@ -698,6 +746,7 @@ extern "C" int t3_engine_add_request(t3_engine* e, int64_t req_id, const int32_t
     r->cond.assign(cond, cond + (size_t)kCondRows * c.d_model);
     r->sp = *sp;
     r->prompt_len = P;
+    r->limit = std::max(1, std::min(sp->max_tokens, c.max_model_len - P));
     r->reserve_pages = pages_for(std::min(P + sp->max_tokens, c.max_model_len));
     e->waiting.push_back(std::move(r));
     return 0;
@@ -708,14 +757,18 @@ extern "C" int t3_engine_abort(t3_engine* e, int64_t req_id) {
     for (auto it = e->waiting.begin(); it != e->waiting.end(); ++it)
         if ((*it)->id == req_id) { e->waiting.erase(it); return 0; }
     for (auto& s : e->slots)
-        if (s && s->id == req_id) { release_request(e, *s); s.reset(); return 0; }
+        if (s && s->id == req_id && !s->zombie) {
+            if (s->n_launched > s->n_out) { s->zombie = true; s->aborted = true; }   // a launched step still uses its pages
+            else { release_request(e, *s); s.reset(); }
+            return 0;
+        }
     t3_set_error("abort: unknown request id");
     return 1;
 }
 
 extern "C" int t3_engine_has_unfinished(t3_engine* e) {
     if (!e) return 0;
-    if (!e->waiting.empty()) return 1;
+    if (!e->waiting.empty() || e->inflight.valid) return 1;
     for (auto& s : e->slots) if (s) return 1;
     return 0;
 }
@@ -764,7 +817,7 @@ extern "C" int t3_engine_last_logits(t3_engine* e, int64_t req_id, float* out) {
     T3_REQUIRE(e && out, "null argument");
     T3_REQUIRE(e->keep_logits, "logit taps are off (t3_engine_set_keep_logits)");
     for (auto& s : e->slots)
-        if (s && s->id == req_id) {
+        if (s && s->id == req_id && !s->zombie) {
             const size_t n = (size_t)e->cfg.speech_vocab + kOffset;
             T3_HIP_CHECK(hipMemcpy(out, e->dbg_logits + (size_t)s->slot * n, n * sizeof(float), hipMemcpyDeviceToHost));
             return 0;
@@ -772,6 +825,46 @@ extern "C" int t3_engine_last_logits(t3_engine* e, int64_t req_id, float* out) {
     t3_set_error("last_logits: request is not running");
     return 1;
 }
+
+namespace {
+
+// Wait for the launched step and report it: one (request, token, finish reason) triple per row it carried.
+int report_inflight(t3_engine* e, int64_t* out_req_ids, int32_t* out_tokens, int32_t* out_finished, int32_t cap,
+                    int32_t* n_out) {
+    t3_engine::InFlight& f = e->inflight;
+    if (!f.valid) return 0;
+    T3_REQUIRE(*n_out + (int)(f.admitted.size() + f.running.size()) <= cap, "output arrays too small");
+    T3_HIP_CHECK(hipEventSynchronize(e->step_done[f.parity]));
+    f.valid = false;
+    if (e->ktiming && ktime_collect(e)) return 1;
+    if (e->timing) {
+        if (!f.admitted.empty()) T3_HIP_CHECK(hipEventElapsedTime(&e->stats.prefill_gpu_ms, e->ev[0], e->ev[1]));
+        if (!f.running.empty()) T3_HIP_CHECK(hipEventElapsedTime(&e->stats.decode_gpu_ms, e->ev[2], e->ev[3]));
+    }
+    int k = *n_out;
+    auto account = [&](Request* r, int32_t tok) {
+        if (r->zombie) {                                      // its token is past a stop or an abort: drop it
+            release_request(e, *r); e->slots[r->slot].reset();
+            return;
+        }
+        r->n_out++;
+        int fin = 0;
+        if (tok == r->sp.stop_token) fin = 1;
+        else if (r->n_out >= r->limit) fin = 2;
+        out_req_ids[k] = r->id; out_tokens[k] = tok; out_finished[k] = fin; ++k;
+        if (!fin) return;
+        if (r->n_launched > r->n_out) r->zombie = true;       // the next step already carries it
+        else { release_request(e, *r); e->slots[r->slot].reset(); }
+    };
+    const int32_t* pt = e->pm[f.parity].out_tokens;
+    const int32_t* dt = e->dm[f.parity].out_tokens;
+    for (size_t i = 0; i < f.admitted.size(); ++i) account(f.admitted[i], pt[i]);
+    for (size_t i = 0; i < f.running.size(); ++i) account(f.running[i], dt[i]);
+    *n_out = k;
+    return 0;
+}
+
+}  // namespace
 
 extern "C" int t3_engine_step(t3_engine* e, int64_t* out_req_ids, int32_t* out_tokens, int32_t* out_finished,
                               int32_t cap, int32_t* n_out) {
@@ -781,10 +874,14 @@ extern "C" int t3_engine_step(t3_engine* e, int64_t* out_req_ids, int32_t* out_t
     const t3_config& c = e->cfg;
     *n_out = 0;
     std::memset(&e->stats, 0, sizeof(e->stats));
+    const bool sync_mode = !e->async_steps || e->timing || e->ktiming || e->keep_logits || e->debug_sync;
+    // a synchronous step must not be planned on stale knowledge: report the launched one first
+    if (sync_mode && report_inflight(e, out_req_ids, out_tokens, out_finished, cap, n_out)) return 1;
 
-    // requests that were running before this step decode; new ones prefill
+    // requests with tokens still to launch decode; new ones prefill
     std::vector<Request*> running, admitted;
-    for (auto& s : e->slots) if (s) running.push_back(s.get());
+    for (auto& s : e->slots)
+        if (s && !s->zombie && s->n_launched < s->limit) running.push_back(s.get());
     int row_budget = c.max_prefill_rows;
     while (!e->waiting.empty()) {
         Request& r = *e->waiting.front();
@@ -801,41 +898,37 @@ extern "C" int t3_engine_step(t3_engine* e, int64_t* out_req_ids, int32_t* out_t
         e->slots[slot] = std::move(e->waiting.front());
         e->waiting.pop_front();
     }
-    T3_REQUIRE((int)(running.size() + admitted.size()) <= cap, "output arrays too small");
 
+    const int q = e->parity;
     if (!admitted.empty()) {
         if (e->timing) T3_HIP_CHECK(hipEventRecord(e->ev[0], e->stream));
         if (run_prefill(e, admitted)) return 1;
         if (e->timing) T3_HIP_CHECK(hipEventRecord(e->ev[1], e->stream));
-        T3_HIP_CHECK(hipMemcpyAsync(e->pm.out_tokens, dev_of(e->pm.i32, e->pm.out_tokens), sizeof(int32_t) * admitted.size(),
-                                    hipMemcpyDeviceToHost, e->stream));
+        T3_HIP_CHECK(hipMemcpyAsync(e->pm[q].out_tokens, dev_of(e->pm[q].i32, e->pm[q].out_tokens),
+                                    sizeof(int32_t) * admitted.size(), hipMemcpyDeviceToHost, e->stream));
+        for (Request* r : admitted) r->n_launched = 1;
     }
     if (!running.empty()) {
         if (e->timing) T3_HIP_CHECK(hipEventRecord(e->ev[2], e->stream));
         if (run_decode(e, running)) return 1;
         if (e->timing) T3_HIP_CHECK(hipEventRecord(e->ev[3], e->stream));
-        T3_HIP_CHECK(hipMemcpyAsync(e->dm.out_tokens, dev_of(e->dm.i32, e->dm.out_tokens), sizeof(int32_t) * running.size(),
-                                    hipMemcpyDeviceToHost, e->stream));
+        T3_HIP_CHECK(hipMemcpyAsync(e->dm[q].out_tokens, dev_of(e->dm[q].i32, e->dm[q].out_tokens),
+                                    sizeof(int32_t) * running.size(), hipMemcpyDeviceToHost, e->stream));
+        for (Request* r : running) r->n_launched++;
     }
-    T3_HIP_CHECK(hipStreamSynchronize(e->stream));
-    if (e->ktiming && ktime_collect(e)) return 1;
-    if (e->timing) {
-        if (!admitted.empty()) T3_HIP_CHECK(hipEventElapsedTime(&e->stats.prefill_gpu_ms, e->ev[0], e->ev[1]));
-        if (!running.empty()) T3_HIP_CHECK(hipEventElapsedTime(&e->stats.decode_gpu_ms, e->ev[2], e->ev[3]));
-    }
+    const bool launched = !admitted.empty() || !running.empty();
+    if (launched) T3_HIP_CHECK(hipEventRecord(e->step_done[q], e->stream));
 
-    int k = 0;
-    auto account = [&](Request* r, int32_t tok) {
-        r->n_out++;
-        int fin = 0;
-        if (tok == r->sp.stop_token) fin = 1;
-        else if (r->n_out >= r->sp.max_tokens || r->prompt_len + r->n_out >= c.max_model_len) fin = 2;
-        out_req_ids[k] = r->id; out_tokens[k] = tok; out_finished[k] = fin; ++k;
-        if (fin) { release_request(e, *r); e->slots[r->slot].reset(); }
-    };
-    for (size_t i = 0; i < admitted.size(); ++i) account(admitted[i], e->pm.out_tokens[i]);
-    for (size_t i = 0; i < running.size(); ++i) account(running[i], e->dm.out_tokens[i]);
-    *n_out = k;
+    // report the previous step while this one runs (in the synchronous modes it was reported above)
+    if (report_inflight(e, out_req_ids, out_tokens, out_finished, cap, n_out)) return 1;
+    if (launched) {
+        e->inflight.valid = true;
+        e->inflight.parity = q;
+        e->inflight.admitted = std::move(admitted);
+        e->inflight.running = std::move(running);
+        e->parity ^= 1;
+        if (sync_mode && report_inflight(e, out_req_ids, out_tokens, out_finished, cap, n_out)) return 1;
+    }
     e->stats.free_pages = (int32_t)e->free_pages.size();
     e->stats.waiting = (int32_t)e->waiting.size();
     int run = 0;

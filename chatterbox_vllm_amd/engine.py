@@ -138,12 +138,15 @@ class T3Engine:
         return rid
 
     def step(self):
-        """One scheduler iteration -> list of (request_id, token_id, finish_reason | None)."""
-        cap = self.max_num_seqs
-        rid = (C.c_int64 * cap)()
-        tok = (C.c_int32 * cap)()
-        fin = (C.c_int32 * cap)()
-        n = C.c_int32(0)
+        """One scheduler iteration -> list of (request_id, token_id, finish_reason | None).
+
+        Steps are pipelined one deep inside the library: a call launches the next step and reports the
+        previous one, so the first call after admission may report nothing and a call that switches to a
+        synchronous mode (timing, logit taps) may report two steps' tokens, in order."""
+        cap = 2 * self.max_num_seqs
+        if getattr(self, "_step_bufs", None) is None:
+            self._step_bufs = ((C.c_int64 * cap)(), (C.c_int32 * cap)(), (C.c_int32 * cap)(), C.c_int32(0))
+        rid, tok, fin, n = self._step_bufs
         _capi.check(self._lib, self._lib.t3_engine_step(self._h, rid, tok, fin, cap, C.byref(n)))
         return [(rid[i], tok[i], _FINISH.get(fin[i])) for i in range(n.value)]
 

@@ -167,6 +167,56 @@ def test_stop_and_length_rules(small):
     eng.shutdown()
 
 
+def test_pipelined_steps_match_synchronous_steps(small, monkeypatch):
+    """One-step-ahead launching (the default) against every step run to completion inside the call:
+    same ids and finish reasons when requests end on stop ids at different steps (so a stopped request
+    rides along for one discarded row), their slots are reused by waiting requests, and a request
+    is aborted while a launched step still carries it."""
+    cfg, sd = small
+    texts = [_text(n, 300 + n) for n in (4, 22, 9, 51, 13, 7, 30, 16)]
+    voices = [i % 3 for i in range(8)]
+    items = _items(texts, voices)
+
+    def sp(stop):
+        return SamplingParams(temperature=0.0, repetition_penalty=2.0, max_tokens=24, stop_token_ids=[stop])
+
+    def run(pipelined, sps):
+        monkeypatch.setenv("T3_ASYNC", "1" if pipelined else "0")
+        eng = T3Engine(cfg, sd, max_model_len=256, max_num_seqs=3, cfg_scale=3.0)
+        outs = eng.generate(items, sps)
+        eng.shutdown()
+        return [(o.outputs[0].token_ids, o.outputs[0].finish_reason) for o in outs]
+
+    free = run(True, [sp(STOP)] * 8)
+    assert all(len(i) == 24 and f == "length" for i, f in free)
+    assert run(False, [sp(STOP)] * 8) == free
+    stops = [free[i][0][k] for i, k in enumerate((0, 5, 23, 11, 1, 17, 8, 3))]
+    want = [(ids[:ids.index(s) + 1], "stop") for (ids, _), s in zip(free, stops)]
+    assert run(True, [sp(s) for s in stops]) == want
+    assert run(False, [sp(s) for s in stops]) == want
+
+    # abort in mid-flight: the others are unaffected, the aborted id goes quiet, the slot is reusable
+    monkeypatch.setenv("T3_ASYNC", "1")
+    eng = T3Engine(cfg, sd, max_model_len=256, max_num_seqs=3, cfg_scale=3.0)
+    rids = [eng.add_request(items[i]["prompt_token_ids"], items[i]["multi_modal_data"]["conditionals"][0], sp(STOP))
+            for i in range(4)]
+    got = {r: [] for r in rids}
+    n_steps, after_abort = 0, 0
+    while eng.has_unfinished():
+        for rid, tok, _ in eng.step():
+            got[rid].append(tok)
+            after_abort += int(n_steps > 3 and rid == rids[1])
+        n_steps += 1
+        if n_steps == 3:
+            eng.abort(rids[1])
+    assert after_abort == 0 and len(got[rids[1]]) < 24
+    for j in (0, 2, 3):
+        assert got[rids[j]] == free[j][0]
+    again = eng.generate(items[:3], sp(STOP))
+    assert [o.outputs[0].token_ids for o in again] == [free[j][0] for j in range(3)]
+    eng.shutdown()
+
+
 def test_multilingual_ids_collide_with_speech_columns_as_in_reference():
     """Text ids >= 1000 of the multilingual vocabulary land on speech columns id-1000 of the
     repetition-penalty set (the sampler sees prompt ids and output ids in one id space)."""

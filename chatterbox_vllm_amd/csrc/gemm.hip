@@ -62,6 +62,7 @@ __global__ __launch_bounds__(KW * 64) void gemm_stream_kernel(GemmArgs a) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[nb][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    T3_STAMP(0);
     const int kt0 = (blockIdx.z * KW + w) * KT;       // blockIdx.z > 0 only for split-K slabs
     // activation row addresses first: the row gather (head GEMM only) is a dependent load, and a
     // wait for it placed after the weight loads would also wait for the whole HBM stream
@@ -73,13 +74,38 @@ __global__ __launch_bounds__(KW * 64) void gemm_stream_kernel(GemmArgs a) {
         if constexpr (EPI == EPI_STORE_GATHER) r = a.a_rows[r];
         arow[mt] = a.A + (size_t)r * a.lda + kt0 * 32 + 8 * (lane >> 4);
     }
-    // weight fragments: the HBM stream, issued first
+    // QKV epilogue operands (position, rope row, KV page) hang off two levels of dependent loads;
+    // fetched here, ahead of and underneath the weight stream, they cost nothing at the end.
+    int pre_pos = 0, pre_st = -1;
+    if constexpr (EPI == EPI_QKV_ROPE) {
+        static_assert(MT <= KW, "each wave finishes at most one row tile");
+        if (w < MT) {
+            int r = m0 + w * 16 + (lane & 15);
+            r = r < a.M ? r : a.M - 1;
+            pre_pos = a.pos[r];
+            if (region >= 1) pre_st = a.row_stream[r];
+        }
+    }
+    // weight fragments: the HBM stream
     bf16x8 wf[NB][KT];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const bf16x8* wp = reinterpret_cast<const bf16x8*>(a.Wt) + ((size_t)nbi[nb] * ktiles + kt0) * 64 + lane;
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) wf[nb][kt] = __builtin_nontemporal_load(wp + kt * 64);
+    }
+    u32x2 pre_cs = {0u, 0u}, pre_sn = {0u, 0u};
+    int pre_page = 0;
+    if constexpr (EPI == EPI_QKV_ROPE) {
+        if (w < MT) {
+            if (region < 2) {
+                const bf16_t* tb = a.rope + (size_t)pre_pos * a.kv.hd + half * 16 + 4 * (lane >> 4);
+                pre_cs = *reinterpret_cast<const u32x2*>(tb);
+                pre_sn = *reinterpret_cast<const u32x2*>(tb + 32);
+            }
+            if (region >= 1 && pre_st >= 0)
+                pre_page = a.kv.block_table[(size_t)pre_st * a.kv.max_pages + (pre_pos >> 6)];
+        }
     }
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) {
@@ -93,12 +119,18 @@ __global__ __launch_bounds__(KW * 64) void gemm_stream_kernel(GemmArgs a) {
                 acc[nb][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb][kt], af[mt], acc[nb][mt], 0, 0, 0);
     }
 
+    T3_STAMP(1);
+#ifdef T3_GEMM_TIMELINE
+    if (acc[0][0][0] == 1.2345e-30f) a.ts[0] = 0;     // pins stamp 2 behind the arrival of the MFMA results
+#endif
+    T3_STAMP(2);
     // cross-wave K reduction through LDS, fixed order
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) red[(w * NT + nb * MT + mt) * 64 + lane] = acc[nb][mt];
     __syncthreads();
+    T3_STAMP(3);
 
     for (int mt = w; mt < MT; mt += KW) {
         f32x4 s[NB];
@@ -155,13 +187,11 @@ __global__ __launch_bounds__(KW * 64) void gemm_stream_kernel(GemmArgs a) {
             float x[4], y[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) { x[i] = rbf(s[0][i]); y[i] = rbf(s[1][i]); }
-            const int pos = a.pos[r];
+            const int pos = pre_pos;
             int c0, c1;                                   // column inside the head of x[0], y[0]
             if (region < 2) {
                 c0 = half * 16 + nl; c1 = c0 + 32;
-                const bf16_t* tb = a.rope + (size_t)pos * hd;
-                const u32x2 cs = *reinterpret_cast<const u32x2*>(tb + c0);
-                const u32x2 sn = *reinterpret_cast<const u32x2*>(tb + 32 + c0);
+                const u32x2 cs = pre_cs, sn = pre_sn;
                 const float c[4] = {bf_lo(cs[0]), bf_hi(cs[0]), bf_lo(cs[1]), bf_hi(cs[1])};
                 const float sv[4] = {bf_lo(sn[0]), bf_hi(sn[0]), bf_lo(sn[1]), bf_hi(sn[1])};
 #pragma unroll
@@ -179,9 +209,8 @@ __global__ __launch_bounds__(KW * 64) void gemm_stream_kernel(GemmArgs a) {
             *reinterpret_cast<u32x2*>(qrow + c0) = ox;
             *reinterpret_cast<u32x2*>(qrow + c1) = oy;
             if (region >= 1) {
-                const int st = a.row_stream[r];
-                if (st >= 0) {
-                    const int page = a.kv.block_table[(size_t)st * a.kv.max_pages + (pos >> 6)];
+                if (pre_st >= 0) {
+                    const int page = pre_page;
                     bf16_t* base = a.kv.pool + (size_t)a.layer * a.kv.layer_stride +
                                    ((size_t)page * 2 + (region - 1)) * ((size_t)H * T3_PAGE * hd) +
                                    ((size_t)head * T3_PAGE + (pos & 63)) * hd;
@@ -191,6 +220,7 @@ __global__ __launch_bounds__(KW * 64) void gemm_stream_kernel(GemmArgs a) {
             }
         }
     }
+    T3_STAMP(4);
 }
 
 // Tile repack: one thread per 8 consecutive k of one W row.

@@ -68,7 +68,21 @@ struct GemmArgs {
     KvView kv; int layer;
     // EPI_SLAB
     float* slab;                       // [GEMM_SLAB_SPLIT][M][N] fp32 partial sums
+#ifdef T3_GEMM_TIMELINE
+    long long* ts;                     // tools/gemm_timeline.hip: [block][wave][8] wall-clock stamps
+#endif
 };
+// Stage stamps for the stand-alone timeline tool; nothing in the shipped library.
+#ifdef T3_GEMM_TIMELINE
+#define T3_STAMP(i)                                                                                       \
+    do {                                                                                                  \
+        if (lane == 0)                                                                                    \
+            a.ts[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 128 + w * 8 + (i)] = \
+                wall_clock64();                                                                           \
+    } while (0)
+#else
+#define T3_STAMP(i) do { } while (0)
+#endif
 int launch_gemm(int epi, const GemmArgs& a, hipStream_t st);
 int launch_gemm_slab(const GemmArgs& a, hipStream_t st);
 // res = bf16(bf16(sum_s slab[s]) + res) when slab != nullptr (nsplit slabs of [rows, d] fp32);

@@ -172,6 +172,7 @@ struct t3_engine {
     double kms[2][K_NCLASS] = {};
     int64_t klaunches[2][K_NCLASS] = {};
     int64_t kbytes[2][K_NCLASS] = {};
+    double k_overhead_ms = 0.0;                         // what an empty event bracket measures
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 
     KvView kvview() const {
@@ -792,7 +793,29 @@ extern "C" int t3_engine_set_kernel_timing(t3_engine* e, int32_t on) {
         std::memset(e->kms, 0, sizeof(e->kms));
         std::memset(e->klaunches, 0, sizeof(e->klaunches));
         std::memset(e->kbytes, 0, sizeof(e->kbytes));
+        // calibrate: empty brackets, recorded the way ktime_begin / ktime_end record them
+        T3_HIP_CHECK(hipSetDevice(e->cfg.device));
+        T3_HIP_CHECK(hipStreamSynchronize(e->stream));
+        constexpr int kN = 256;
+        std::vector<hipEvent_t> evs(2 * kN);
+        for (auto& ev : evs) T3_HIP_CHECK(hipEventCreate(&ev));
+        for (int i = 0; i < 2 * kN; ++i) T3_HIP_CHECK(hipEventRecord(evs[i], e->stream));
+        T3_HIP_CHECK(hipStreamSynchronize(e->stream));
+        double sum = 0.0;
+        for (int i = 0; i < kN; ++i) {
+            float ms = 0.f;
+            T3_HIP_CHECK(hipEventElapsedTime(&ms, evs[2 * i], evs[2 * i + 1]));
+            sum += ms;
+        }
+        for (auto& ev : evs) (void)hipEventDestroy(ev);
+        e->k_overhead_ms = sum / kN;
     }
+    return 0;
+}
+
+extern "C" int t3_engine_get_kernel_timing_overhead(t3_engine* e, double* ms_per_bracket) {
+    T3_REQUIRE(e && ms_per_bracket, "null argument");
+    *ms_per_bracket = e->k_overhead_ms;
     return 0;
 }
 

@@ -176,6 +176,12 @@ class T3Engine:
         return {self._lib.t3_kernel_class_name(i).decode(): {"ms": ms[i], "launches": cnt[i], "bytes": byt[i]}
                 for i in range(n) if cnt[i]}
 
+    def kernel_timing_overhead_ms(self) -> float:
+        """What one empty event bracket measured when kernel timing was switched on."""
+        v = C.c_double(0.0)
+        _capi.check(self._lib, self._lib.t3_engine_get_kernel_timing_overhead(self._h, C.byref(v)))
+        return v.value
+
     def set_keep_logits(self, on: bool) -> None:
         _capi.check(self._lib, self._lib.t3_engine_set_keep_logits(self._h, int(on)))
 

@@ -110,6 +110,11 @@ const char* t3_kernel_class_name(int32_t cls);
 /* phase 0 = decode steps, 1 = prefill.  Arrays of n >= t3_kernel_class_count() entries:
  * total milliseconds, launches, and algorithmic bytes (weights or KV a launch must read). */
 int t3_engine_get_kernel_times(t3_engine* e, int32_t phase, double* ms, int64_t* launches, int64_t* bytes, int32_t n);
+/* Milliseconds an EMPTY event bracket measures on the engine's stream (mean of 256 brackets taken when
+ * kernel timing was switched on): the part of every bracketed launch that is not the kernel.  The totals
+ * of t3_engine_get_kernel_times are raw; subtract launches * this to compare with a profiler's kernel
+ * durations. */
+int t3_engine_get_kernel_timing_overhead(t3_engine* e, double* ms_per_bracket);
 
 /* ---- debugging taps for parity tests ------------------------------------------- */
 /* Keep the CFG-combined, penalised fp32 logits of every sampled token (turns graph replay

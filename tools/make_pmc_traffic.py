@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""profiles/pmc_traffic.json from the two --pmc pass summaries of tools/profile_round.sh:
+   python3 tools/make_pmc_traffic.py gpurun_out/r01 > profiles/pmc_traffic.json
+Keys are the engine's kernel classes; bytes_per_launch = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes), the
+mean over every launch of that kernel in one pass of the benchmark job."""
+import json, sys
+tag = sys.argv[1]
+f = json.load(open(tag + "_pmc_fetch.json"))["FETCH_SIZE"]
+w = json.load(open(tag + "_pmc_write.json"))["WRITE_SIZE"]
+classes = {
+    "attn_decode": ["attn_decode_kernel"],
+    "gemm_gateup_silu": ["void gemm_stream_kernel<2, 4, 8, 4, 2>"],
+    "gemm_qkv_rope": ["void gemm_stream_kernel<2, 4, 8, 4, 3>"],
+    "gemm_down_resid": ["void gemm_stream_kernel<2, 4, 8, 2, 4>"],
+    "gemm_o_resid": ["void gemm_stream_kernel<2, 4, 4, 1, 4>"],
+    "add_rmsnorm": ["void slab_add_rmsnorm_kernel<8>"],
+}
+out = {}
+for cls, names in classes.items():
+    for n in names:
+        if n in f:
+            fb, wb = f[n]["bytes_corrected"], w.get(n, {}).get("bytes_corrected", 0.0)
+            out[cls] = {"bytes_per_launch": round(fb + wb), "fetch_bytes": round(fb), "write_bytes": round(wb),
+                        "dispatches": f[n]["dispatches"], "kernel": n,
+                        "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over one pass of the "
+                                  "default bench.py job, graphs off; FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B); "
+                                  "row-tile-4 variants (33-64 rows) for the projections"}
+json.dump(out, sys.stdout, indent=1)
+print()

@@ -89,8 +89,12 @@ int t3_engine_add_request(t3_engine* e, int64_t req_id, const int32_t* text_ids,
                           const float* cond, const t3_sampling* sp);
 /* One scheduler iteration: admit + prefill new requests, decode one token for every
  * running request.  out_* have room for `cap` entries; *n_out receives the number of
- * (req_id, token, finished) triples produced.  finished: 0 running, 1 stop token,
- * 2 length.  Tokens are in the +1000 id space, the stop token is reported. */
+ * (req_id, token, finished) triples reported.  finished: 0 running, 1 stop token,
+ * 2 length.  Tokens are in the +1000 id space, the stop token is reported.
+ * Iterations are pipelined one deep: a call launches the next iteration and reports the
+ * previous one, so a call may report nothing (the first after admission) and, when a
+ * measuring mode has just been switched on, two iterations' triples in order; give
+ * cap >= 2 * max_num_seqs and loop while t3_engine_has_unfinished(). */
 int t3_engine_step(t3_engine* e, int64_t* out_req_ids, int32_t* out_tokens, int32_t* out_finished,
                    int32_t cap, int32_t* n_out);
 int t3_engine_abort(t3_engine* e, int64_t req_id);

@@ -200,14 +200,7 @@ def main():
         run_job(eng, job, cond)
         timed_pass = time.perf_counter() - t1
         kd, kp = eng.kernel_times("decode"), eng.kernel_times("prefill")
-        # An event bracket also measures the two packet hops around the kernel (event -> kernel -> event); an
-        # empty bracket measures one hop.  Kernel time = bracket - 2 hops, which is what a profiler reports.
-        hop_ms = eng.kernel_timing_overhead_ms()
         eng.set_kernel_timing(False)
-        for d in (kd, kp):
-            for v in d.values():
-                v["raw_ms"] = v["ms"]
-                v["ms"] = max(v["ms"] - 2.0 * hop_ms * v["launches"], 0.05 * v["ms"])
         tot = sum(v["ms"] for v in kd.values()) + sum(v["ms"] for v in kp.values())
         name, dom = max(kd.items(), key=lambda kv: kv[1]["ms"])
         per_launch_bytes = dom["bytes"] / dom["launches"]
@@ -217,7 +210,6 @@ def main():
             "bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
             "avg_launch_us": round(per_launch_s * 1e6, 2),
-            "avg_bracket_us": round(dom["raw_ms"] / dom["launches"] * 1e3, 2), "event_hop_us": round(hop_ms * 1e3, 2),
             "algorithmic_bytes_per_launch": int(per_launch_bytes),
             "launches": dom["launches"], "share_of_gpu_time": round(dom["ms"] / tot, 3),
         }

@@ -68,7 +68,6 @@ SIGNATURES = {
     "t3_kernel_class_name": ([C.c_int32], C.c_char_p),
     "t3_engine_get_kernel_times": ([_P, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                     C.c_int32], C.c_int),
-    "t3_engine_get_kernel_timing_overhead": ([_P, C.POINTER(C.c_double)], C.c_int),
     "t3_engine_set_keep_logits": ([_P, C.c_int32], C.c_int),
     "t3_engine_last_logits": ([_P, C.c_int64, C.POINTER(C.c_float)], C.c_int),
     "t3_op_repack_weight": ([_P, _P, C.c_int32, C.c_int32, _P], C.c_int),

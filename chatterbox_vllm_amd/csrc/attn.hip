@@ -130,7 +130,7 @@ int launch_attn_decode(const bf16_t* qkv, int ldq, bf16_t* out, int rows, const 
                        const int32_t* row_ctx, const KvView& kv, int layer, hipStream_t st) {
     T3_REQUIRE(kv.hd == 64, "attn_decode: head_dim must be 64");
     T3_REQUIRE(rows >= 1 && ldq % 8 == 0, "attn_decode: bad shape");
-    hipLaunchKernelGGL(attn_decode_kernel, dim3(kv.H, rows), dim3(ATT_NW * 64), 0, st, qkv, ldq, out,
+    T3_LAUNCH(attn_decode_kernel, dim3(kv.H, rows), dim3(ATT_NW * 64), 0, st, qkv, ldq, out,
                        kv.H * kv.hd, row_stream, row_ctx, kv, layer);
     T3_HIP_CHECK(hipGetLastError());
     return 0;
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const bf16_t* __restr
 int launch_attn_prefill(const bf16_t* qkv, int ldq, bf16_t* out, const int32_t* seq_start_dev,
                         const int32_t* tiles_dev, int ntiles, int H, int hd, hipStream_t st) {
     T3_REQUIRE(hd == 64 && ntiles >= 1, "attn_prefill: head_dim must be 64");
-    hipLaunchKernelGGL(attn_prefill_kernel, dim3(ntiles, H), dim3(256), 0, st, qkv, ldq, out, H * hd, seq_start_dev,
+    T3_LAUNCH(attn_prefill_kernel, dim3(ntiles, H), dim3(256), 0, st, qkv, ldq, out, H * hd, seq_start_dev,
                        tiles_dev, H);
     T3_HIP_CHECK(hipGetLastError());
     return 0;

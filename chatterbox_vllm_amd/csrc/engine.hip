@@ -172,7 +172,6 @@ struct t3_engine {
     double kms[2][K_NCLASS] = {};
     int64_t klaunches[2][K_NCLASS] = {};
     int64_t kbytes[2][K_NCLASS] = {};
-    double k_overhead_ms = 0.0;                         // what an empty event bracket measures
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 
     KvView kvview() const {
@@ -187,7 +186,7 @@ template <typename T>
 T* carve(T*& base, size_t n) { T* p = base; base += n; return p; }
 
 // With T3_DEBUG_SYNC=1 every launch is followed by a synchronize, so a faulting kernel is named.
-// In kernel-timing mode every launch is bracketed by two HIP events on the engine's stream.
+// In kernel-timing mode every launch carries two HIP events bound to its own dispatch.
 int stage_check(t3_engine* e, const char* label, int layer = -1);
 int ktime_begin(t3_engine* e, int cls, int64_t bytes);
 int ktime_end(t3_engine* e);
@@ -249,12 +248,16 @@ int ktime_begin(t3_engine* e, int cls, int64_t bytes) {
         }
     }
     e->kpending.push_back({e->kphase, cls, (int)e->kused, bytes});
-    T3_HIP_CHECK(hipEventRecord(e->kpool[e->kused], e->stream));
+    t3_launch_events = T3LaunchEvents{e->kpool[e->kused], e->kpool[e->kused + 1]};   // consumed by the next T3_LAUNCH
     return 0;
 }
 int ktime_end(t3_engine* e) {
     if (!e->ktiming) return 0;
-    T3_HIP_CHECK(hipEventRecord(e->kpool[e->kused + 1], e->stream));
+    if (t3_launch_events.start) {                     // the call launched nothing
+        t3_launch_events = T3LaunchEvents{nullptr, nullptr};
+        e->kpending.pop_back();
+        return 0;
+    }
     e->kused += 2;
     return 0;
 }
@@ -793,29 +796,7 @@ extern "C" int t3_engine_set_kernel_timing(t3_engine* e, int32_t on) {
         std::memset(e->kms, 0, sizeof(e->kms));
         std::memset(e->klaunches, 0, sizeof(e->klaunches));
         std::memset(e->kbytes, 0, sizeof(e->kbytes));
-        // calibrate: empty brackets, recorded the way ktime_begin / ktime_end record them
-        T3_HIP_CHECK(hipSetDevice(e->cfg.device));
-        T3_HIP_CHECK(hipStreamSynchronize(e->stream));
-        constexpr int kN = 256;
-        std::vector<hipEvent_t> evs(2 * kN);
-        for (auto& ev : evs) T3_HIP_CHECK(hipEventCreate(&ev));
-        for (int i = 0; i < 2 * kN; ++i) T3_HIP_CHECK(hipEventRecord(evs[i], e->stream));
-        T3_HIP_CHECK(hipStreamSynchronize(e->stream));
-        double sum = 0.0;
-        for (int i = 0; i < kN; ++i) {
-            float ms = 0.f;
-            T3_HIP_CHECK(hipEventElapsedTime(&ms, evs[2 * i], evs[2 * i + 1]));
-            sum += ms;
-        }
-        for (auto& ev : evs) (void)hipEventDestroy(ev);
-        e->k_overhead_ms = sum / kN;
     }
-    return 0;
-}
-
-extern "C" int t3_engine_get_kernel_timing_overhead(t3_engine* e, double* ms_per_bracket) {
-    T3_REQUIRE(e && ms_per_bracket, "null argument");
-    *ms_per_bracket = e->k_overhead_ms;
     return 0;
 }
 

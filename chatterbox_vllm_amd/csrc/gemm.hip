@@ -238,7 +238,7 @@ __global__ void repack_kernel(const bf16_t* __restrict__ w, bf16_t* __restrict__
 int launch_repack(const bf16_t* w, bf16_t* wt, int N, int K, hipStream_t st) {
     T3_REQUIRE(N % 16 == 0 && K % 32 == 0, "repack: N must be a multiple of 16 and K of 32");
     const size_t n = (size_t)N * (K / 8);
-    hipLaunchKernelGGL(repack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, wt, N, K);
+    T3_LAUNCH(repack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, wt, N, K);
     T3_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -253,7 +253,7 @@ static int launch_one(const GemmArgs& a, int nblocks, hipStream_t st, int ksplit
         attr_set = true;
     }
     const int groups = (a.M + MT * 16 - 1) / (MT * 16);
-    hipLaunchKernelGGL((gemm_stream_kernel<NB, MT, KW, KT, EPI>), dim3(nblocks, groups, ksplit), dim3(KW * 64), lds, st, a);
+    T3_LAUNCH((gemm_stream_kernel<NB, MT, KW, KT, EPI>), dim3(nblocks, groups, ksplit), dim3(KW * 64), lds, st, a);
     T3_HIP_CHECK(hipGetLastError());
     return 0;
 }

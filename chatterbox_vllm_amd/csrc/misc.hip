@@ -115,9 +115,9 @@ int launch_slab_add_rmsnorm(const float* slab, int nsplit, bf16_t* res, const bf
     T3_REQUIRE(rows >= 1 && d == 1024, "slab_add_rmsnorm: d must be 1024");
     T3_REQUIRE(nsplit == 0 || (slab != nullptr && nsplit == GEMM_SLAB_SPLIT), "slab_add_rmsnorm: nsplit must be 0 or the split count");
     if (nsplit == 0)
-        hipLaunchKernelGGL(slab_add_rmsnorm_kernel<0>, dim3(rows), dim3(128), 0, st, slab, (size_t)rows * d, res, w, xn, eps);
+        T3_LAUNCH(slab_add_rmsnorm_kernel<0>, dim3(rows), dim3(128), 0, st, slab, (size_t)rows * d, res, w, xn, eps);
     else
-        hipLaunchKernelGGL(slab_add_rmsnorm_kernel<GEMM_SLAB_SPLIT>, dim3(rows), dim3(128), 0, st, slab, (size_t)rows * d, res, w, xn, eps);
+        T3_LAUNCH(slab_add_rmsnorm_kernel<GEMM_SLAB_SPLIT>, dim3(rows), dim3(128), 0, st, slab, (size_t)rows * d, res, w, xn, eps);
     T3_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -125,7 +125,7 @@ int launch_slab_add_rmsnorm(const float* slab, int nsplit, bf16_t* res, const bf
 int launch_add_rmsnorm(const bf16_t* x, bf16_t* res, const bf16_t* w, bf16_t* xn, int rows, int d,
                        float eps, hipStream_t st) {
     T3_REQUIRE(rows >= 1 && d % 8 == 0, "add_rmsnorm: d must be a multiple of 8");
-    hipLaunchKernelGGL(add_rmsnorm_kernel, dim3(rows), dim3(128), 0, st, x, res, w, xn, d, eps);
+    T3_LAUNCH(add_rmsnorm_kernel, dim3(rows), dim3(128), 0, st, x, res, w, xn, d, eps);
     T3_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(128) void embed_kernel(EmbedArgs a) {
 
 int launch_embed(const EmbedArgs& a, hipStream_t st) {
     T3_REQUIRE(a.rows >= 1 && a.d % 8 == 0, "embed: bad shape");
-    hipLaunchKernelGGL(embed_kernel, dim3(a.rows), dim3(128), 0, st, a);
+    T3_LAUNCH(embed_kernel, dim3(a.rows), dim3(128), 0, st, a);
     T3_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -350,7 +350,7 @@ int launch_sample(const SampleArgs& a, hipStream_t st) {
     T3_REQUIRE(a.n >= 1 && a.vocab <= SAMPLE_MAX_VOCAB, "sample: vocab too large");
     T3_REQUIRE(a.seen_stride >= a.vocab + 1000 && a.seen_stride % 8 == 0, "sample: seen rows too short or unaligned");
     T3_REQUIRE(a.ldl % 8 == 0, "sample: logits row stride must be a multiple of 8");
-    hipLaunchKernelGGL(sample_kernel, dim3(a.n), dim3(SAMPLE_THREADS), 0, st, a);
+    T3_LAUNCH(sample_kernel, dim3(a.n), dim3(SAMPLE_THREADS), 0, st, a);
     T3_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256) void seen_init_kernel(uint8_t* seen, int strid
 
 int launch_seen_init(uint8_t* seen_row, int seen_stride, const int32_t* ids_dev, int n_ids, hipStream_t st) {
     T3_REQUIRE(seen_stride % 4 == 0, "seen_init: stride must be a multiple of 4");
-    hipLaunchKernelGGL(seen_init_kernel, dim3(1), dim3(256), 0, st, seen_row, seen_stride, ids_dev, n_ids);
+    T3_LAUNCH(seen_init_kernel, dim3(1), dim3(256), 0, st, seen_row, seen_stride, ids_dev, n_ids);
     T3_HIP_CHECK(hipGetLastError());
     return 0;
 }

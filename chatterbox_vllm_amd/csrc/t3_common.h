@@ -1,6 +1,7 @@
 // Shared device helpers and the internal launcher interface of the T3 engine (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <string>
 
@@ -44,6 +45,22 @@ void t3_set_error(const std::string& msg);
 // ---- KV cache geometry -------------------------------------------------------------
 // pool[layer][page][kv(0=K,1=V)][head][token(64)][head_dim]   bf16
 // layer_stride = n_pages * 2 * H * 64 * hd elements.
+// Every kernel of the library is launched through T3_LAUNCH.  When the engine's kernel-timing mode has
+// armed a pair of events, the launch binds them to the dispatch itself, so that their elapsed time is
+// the kernel's own start-to-end time on the device (what a profiler reports), not a stream bracket.
+struct T3LaunchEvents { hipEvent_t start, stop; };
+inline thread_local T3LaunchEvents t3_launch_events = {nullptr, nullptr};
+#define T3_LAUNCH(kernel, grid, block, lds, st, ...)                                                        \
+    do {                                                                                                    \
+        if (t3_launch_events.start) {                                                                       \
+            hipExtLaunchKernelGGL(kernel, grid, block, lds, st, t3_launch_events.start,                     \
+                                  t3_launch_events.stop, 0, __VA_ARGS__);                                   \
+            t3_launch_events = T3LaunchEvents{nullptr, nullptr};                                            \
+        } else {                                                                                            \
+            hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                                  \
+        }                                                                                                   \
+    } while (0)
+
 struct KvView {
     bf16_t* pool;
     int64_t layer_stride;        // elements

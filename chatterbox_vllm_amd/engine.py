@@ -165,7 +165,7 @@ class T3Engine:
         _capi.check(self._lib, self._lib.t3_engine_set_timing(self._h, int(on)))
 
     def set_kernel_timing(self, on: bool) -> None:
-        """Bracket every kernel launch with HIP events (eager launches while on)."""
+        """Time every kernel launch with HIP events bound to its dispatch (eager launches while on)."""
         _capi.check(self._lib, self._lib.t3_engine_set_kernel_timing(self._h, int(on)))
 
     def kernel_times(self, phase: str = "decode") -> Dict[str, dict]:
@@ -175,12 +175,6 @@ class T3Engine:
         _capi.check(self._lib, self._lib.t3_engine_get_kernel_times(self._h, 0 if phase == "decode" else 1, ms, cnt, byt, n))
         return {self._lib.t3_kernel_class_name(i).decode(): {"ms": ms[i], "launches": cnt[i], "bytes": byt[i]}
                 for i in range(n) if cnt[i]}
-
-    def kernel_timing_overhead_ms(self) -> float:
-        """What one empty event bracket measured when kernel timing was switched on."""
-        v = C.c_double(0.0)
-        _capi.check(self._lib, self._lib.t3_engine_get_kernel_timing_overhead(self._h, C.byref(v)))
-        return v.value
 
     def set_keep_logits(self, on: bool) -> None:
         _capi.check(self._lib, self._lib.t3_engine_set_keep_logits(self._h, int(on)))

@@ -104,8 +104,10 @@ int t3_engine_get_stats(t3_engine* e, t3_step_stats* out);
 int t3_engine_set_timing(t3_engine* e, int32_t on);
 
 /* ---- measurement: per-launch HIP-event timing by kernel class.  While on, decode steps are
- *      launched eagerly (no graph replay) and every kernel launch is bracketed by two events on
- *      the engine's stream; totals accumulate until the next t3_engine_set_kernel_timing(e, 1).
+ *      launched eagerly (no graph replay) and every kernel launch carries a start and a stop
+ *      event bound to its own dispatch (hipExtLaunchKernelGGL) on the engine's stream, so a
+ *      launch's time is the kernel's start-to-end time on the device; totals accumulate until
+ *      the next t3_engine_set_kernel_timing(e, 1).
  *      No counterpart in the reference (its only timing is wall clock around LLM.generate,
  *      src/chatterbox_vllm/tts.py:407-420). ------------------------------------------------- */
 int t3_engine_set_kernel_timing(t3_engine* e, int32_t on);
@@ -114,11 +116,6 @@ const char* t3_kernel_class_name(int32_t cls);
 /* phase 0 = decode steps, 1 = prefill.  Arrays of n >= t3_kernel_class_count() entries:
  * total milliseconds, launches, and algorithmic bytes (weights or KV a launch must read). */
 int t3_engine_get_kernel_times(t3_engine* e, int32_t phase, double* ms, int64_t* launches, int64_t* bytes, int32_t n);
-/* Milliseconds an EMPTY event bracket measures on the engine's stream (mean of 256 brackets taken when
- * kernel timing was switched on): the part of every bracketed launch that is not the kernel.  The totals
- * of t3_engine_get_kernel_times are raw; subtract launches * this to compare with a profiler's kernel
- * durations. */
-int t3_engine_get_kernel_timing_overhead(t3_engine* e, double* ms_per_bracket);
 
 /* ---- debugging taps for parity tests ------------------------------------------- */
 /* Keep the CFG-combined, penalised fp32 logits of every sampled token (turns graph replay

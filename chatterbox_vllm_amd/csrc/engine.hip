@@ -288,13 +288,9 @@ int run_layers(t3_engine* e, int rows, const int32_t* d_pos, const int32_t* d_st
     const KvView kv = e->kvview();
     for (int li = 0; li < c.n_layers; ++li) {
         const Layer& L = e->layers[li];
-        // decode: o_proj / down_proj leave split-K partial slabs, folded in by the next norm kernel;
-        // prefill: they add the residual in their own epilogue and the norm only normalises.
-        if (prefill)
-            T3_RUN(e, K_NORM, li, 4LL * rows * D, launch_add_rmsnorm(nullptr, e->b->res, L.ln1, e->b->xn, rows, D, c.rms_eps, st));
-        else
-            T3_RUN(e, K_NORM, li, 4LL * rows * D, launch_slab_add_rmsnorm(e->b->slab, li > 0 ? GEMM_SLAB_SPLIT : 0, e->b->res, L.ln1,
-                                                                          e->b->xn, rows, D, c.rms_eps, st));
+        // o_proj / down_proj leave split-K partial slabs, folded in by the next norm kernel
+        T3_RUN(e, K_NORM, li, 4LL * rows * D, launch_slab_add_rmsnorm(e->b->slab, li > 0 ? GEMM_SLAB_SPLIT : 0, e->b->res, L.ln1,
+                                                                      e->b->xn, rows, D, c.rms_eps, st));
         GemmArgs g{};
         g.A = e->b->xn; g.lda = D; g.Wt = L.wqkv; g.C = e->b->qkv; g.ldc = 3 * D; g.M = rows; g.N = 3 * D; g.K = D;
         g.n_valid = 3 * D; g.rope = e->rope; g.pos = d_pos; g.row_stream = d_stream; g.kv = kv; g.layer = li;
@@ -307,28 +303,19 @@ int run_layers(t3_engine* e, int rows, const int32_t* d_pos, const int32_t* d_st
         GemmArgs o{};
         o.A = e->b->att; o.lda = D; o.Wt = L.wo; o.C = e->b->res; o.ldc = D; o.M = rows; o.N = D; o.K = D; o.n_valid = D;
         o.slab = e->b->slab;
-        if (prefill) {
-            T3_RUN(e, K_OPROJ, li, 2LL * D * D, launch_gemm(EPI_RESID, o, st));
-            T3_RUN(e, K_NORM, li, 4LL * rows * D, launch_add_rmsnorm(nullptr, e->b->res, L.ln2, e->b->xn, rows, D, c.rms_eps, st));
-        } else {
-            T3_RUN(e, K_OPROJ, li, 2LL * D * D, launch_gemm_slab(o, st));
-            T3_RUN(e, K_NORM, li, 4LL * rows * D, launch_slab_add_rmsnorm(e->b->slab, GEMM_SLAB_SPLIT, e->b->res, L.ln2, e->b->xn, rows, D,
-                                                                          c.rms_eps, st));
-        }
+        T3_RUN(e, K_OPROJ, li, 2LL * D * D, launch_gemm_slab(o, st));
+        T3_RUN(e, K_NORM, li, 4LL * rows * D, launch_slab_add_rmsnorm(e->b->slab, GEMM_SLAB_SPLIT, e->b->res, L.ln2, e->b->xn, rows, D,
+                                                                      c.rms_eps, st));
         GemmArgs u{};
         u.A = e->b->xn; u.lda = D; u.Wt = L.wgu; u.C = e->b->hbuf; u.ldc = F; u.M = rows; u.N = 2 * F; u.K = D; u.n_valid = 2 * F;
         T3_RUN(e, K_GATEUP, li, 2LL * 2 * F * D, launch_gemm(EPI_SILU, u, st));
         GemmArgs dn{};
         dn.A = e->b->hbuf; dn.lda = F; dn.Wt = L.wd; dn.C = e->b->res; dn.ldc = D; dn.M = rows; dn.N = D; dn.K = F; dn.n_valid = D;
         dn.slab = e->b->slab;
-        if (prefill) T3_RUN(e, K_DOWN, li, 2LL * F * D, launch_gemm(EPI_RESID, dn, st));
-        else         T3_RUN(e, K_DOWN, li, 2LL * F * D, launch_gemm_slab(dn, st));
+        T3_RUN(e, K_DOWN, li, 2LL * F * D, launch_gemm_slab(dn, st));
     }
-    if (prefill)
-        T3_RUN(e, K_NORM, -1, 4LL * rows * D, launch_add_rmsnorm(nullptr, e->b->res, e->norm_w, e->b->xn, rows, D, c.rms_eps, st));
-    else
-        T3_RUN(e, K_NORM, -1, 4LL * rows * D, launch_slab_add_rmsnorm(e->b->slab, GEMM_SLAB_SPLIT, e->b->res, e->norm_w, e->b->xn, rows, D,
-                                                                      c.rms_eps, st));
+    T3_RUN(e, K_NORM, -1, 4LL * rows * D, launch_slab_add_rmsnorm(e->b->slab, GEMM_SLAB_SPLIT, e->b->res, e->norm_w, e->b->xn, rows, D,
+                                                                  c.rms_eps, st));
     return 0;
 }
 
@@ -586,7 +573,7 @@ extern "C" int t3_engine_create(const t3_config* cfg, t3_engine** out) {
         t3_engine::Bufs& b = e->bufs;
         if (dmalloc(&b.res, R * c.d_model) || dmalloc(&b.xn, R * c.d_model) || dmalloc(&b.qkv, R * 3 * c.d_model) ||
             dmalloc(&b.att, R * c.d_model) || dmalloc(&b.hbuf, R * c.d_ff) || dmalloc(&b.logits, RD * e->head_n)) return 1;
-        T3_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&b.slab), sizeof(float) * GEMM_SLAB_SPLIT * RD * c.d_model));
+        T3_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&b.slab), sizeof(float) * GEMM_SLAB_SPLIT * R * c.d_model));
     }
     e->b = &e->bufs;
     if (const char* ug = getenv("T3_USE_GRAPHS")) e->cfg.use_graphs = atoi(ug) != 0;

@@ -79,6 +79,10 @@ SIGNATURES = {
     "t3_op_gemm_silu": ([_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P], C.c_int),
     "t3_op_gemm_qkv_rope": ([_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int64,
                              C.c_int32, _P, C.c_int32, _P], C.c_int),
+    "t3_op_gemm_prompt_slab": ([_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P], C.c_int),
+    "t3_op_gemm_prompt_silu": ([_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P], C.c_int),
+    "t3_op_gemm_prompt_qkv_rope": ([_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int64,
+                                    C.c_int32, _P, C.c_int32, _P], C.c_int),
     "t3_op_attn_decode": ([_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, C.c_int64, C.c_int32, _P,
                            C.c_int32, _P], C.c_int),
     "t3_op_attn_prefill": ([_P, _P, C.c_int32, _P, _I32P, C.c_int32, C.c_int32, _P], C.c_int),

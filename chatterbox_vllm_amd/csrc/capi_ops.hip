@@ -34,13 +34,22 @@ extern "C" int t3_op_gemm(const void* a_dev, const void* wt_dev, void* out_dev, 
     return launch_gemm(epilogue == 0 ? EPI_STORE : EPI_RESID, g, static_cast<hipStream_t>(stream));
 }
 
-extern "C" int t3_op_gemm_slab(const void* a_dev, const void* wt_dev, float* slab_dev, int32_t M, int32_t N, int32_t K,
-                               void* stream) {
+static int op_slab(bool prompt, const void* a_dev, const void* wt_dev, float* slab_dev, int32_t M, int32_t N, int32_t K,
+                   void* stream) {
     T3_REQUIRE(a_dev && wt_dev && slab_dev, "null argument");
     GemmArgs g{};
     g.A = static_cast<const bf16_t*>(a_dev); g.lda = K; g.Wt = static_cast<const bf16_t*>(wt_dev);
     g.M = M; g.N = N; g.K = K; g.n_valid = N; g.slab = slab_dev;
-    return launch_gemm_slab(g, static_cast<hipStream_t>(stream));
+    return prompt ? launch_gemm_prompt(EPI_SLAB, g, static_cast<hipStream_t>(stream))
+                  : launch_gemm_slab(g, static_cast<hipStream_t>(stream));
+}
+extern "C" int t3_op_gemm_slab(const void* a_dev, const void* wt_dev, float* slab_dev, int32_t M, int32_t N, int32_t K,
+                               void* stream) {
+    return op_slab(false, a_dev, wt_dev, slab_dev, M, N, K, stream);
+}
+extern "C" int t3_op_gemm_prompt_slab(const void* a_dev, const void* wt_dev, float* slab_dev, int32_t M, int32_t N,
+                                      int32_t K, void* stream) {
+    return op_slab(true, a_dev, wt_dev, slab_dev, M, N, K, stream);
 }
 
 extern "C" int t3_op_slab_split(void) { return GEMM_SLAB_SPLIT; }
@@ -52,19 +61,28 @@ extern "C" int t3_op_slab_add_rmsnorm(const float* slab_dev, int32_t nsplit, voi
                                    static_cast<bf16_t*>(xn_dev), rows, d, eps, static_cast<hipStream_t>(stream));
 }
 
-extern "C" int t3_op_gemm_silu(const void* a_dev, const void* wt_dev, void* h_dev, int32_t M, int32_t F, int32_t K,
-                               void* stream) {
+static int op_silu(bool prompt, const void* a_dev, const void* wt_dev, void* h_dev, int32_t M, int32_t F, int32_t K,
+                   void* stream) {
     T3_REQUIRE(a_dev && wt_dev && h_dev, "null argument");
     GemmArgs g{};
     g.A = static_cast<const bf16_t*>(a_dev); g.lda = K; g.Wt = static_cast<const bf16_t*>(wt_dev);
     g.C = static_cast<bf16_t*>(h_dev); g.ldc = F; g.M = M; g.N = 2 * F; g.K = K; g.n_valid = 2 * F;
-    return launch_gemm(EPI_SILU, g, static_cast<hipStream_t>(stream));
+    return prompt ? launch_gemm_prompt(EPI_SILU, g, static_cast<hipStream_t>(stream))
+                  : launch_gemm(EPI_SILU, g, static_cast<hipStream_t>(stream));
+}
+extern "C" int t3_op_gemm_silu(const void* a_dev, const void* wt_dev, void* h_dev, int32_t M, int32_t F, int32_t K,
+                               void* stream) {
+    return op_silu(false, a_dev, wt_dev, h_dev, M, F, K, stream);
+}
+extern "C" int t3_op_gemm_prompt_silu(const void* a_dev, const void* wt_dev, void* h_dev, int32_t M, int32_t F, int32_t K,
+                                      void* stream) {
+    return op_silu(true, a_dev, wt_dev, h_dev, M, F, K, stream);
 }
 
-extern "C" int t3_op_gemm_qkv_rope(const void* a_dev, const void* wt_dev, void* qkv_dev, int32_t M, int32_t H, int32_t hd,
-                                   int32_t K, const void* rope_dev, const int32_t* pos_dev, const int32_t* stream_dev,
-                                   void* kv_pool_dev, int64_t layer_stride_elems, int32_t layer,
-                                   const int32_t* block_table_dev, int32_t max_pages, void* stream) {
+static int op_qkv(bool prompt, const void* a_dev, const void* wt_dev, void* qkv_dev, int32_t M, int32_t H, int32_t hd,
+                  int32_t K, const void* rope_dev, const int32_t* pos_dev, const int32_t* stream_dev,
+                  void* kv_pool_dev, int64_t layer_stride_elems, int32_t layer,
+                  const int32_t* block_table_dev, int32_t max_pages, void* stream) {
     T3_REQUIRE(a_dev && wt_dev && qkv_dev && rope_dev && pos_dev && stream_dev && kv_pool_dev && block_table_dev,
                "null argument");
     GemmArgs g{};
@@ -72,7 +90,22 @@ extern "C" int t3_op_gemm_qkv_rope(const void* a_dev, const void* wt_dev, void* 
     g.C = static_cast<bf16_t*>(qkv_dev); g.ldc = 3 * H * hd; g.M = M; g.N = 3 * H * hd; g.K = K; g.n_valid = g.N;
     g.rope = static_cast<const bf16_t*>(rope_dev); g.pos = pos_dev; g.row_stream = stream_dev;
     g.kv = make_kv(kv_pool_dev, layer_stride_elems, block_table_dev, max_pages, H, hd); g.layer = layer;
-    return launch_gemm(EPI_QKV_ROPE, g, static_cast<hipStream_t>(stream));
+    return prompt ? launch_gemm_prompt(EPI_QKV_ROPE, g, static_cast<hipStream_t>(stream))
+                  : launch_gemm(EPI_QKV_ROPE, g, static_cast<hipStream_t>(stream));
+}
+extern "C" int t3_op_gemm_qkv_rope(const void* a_dev, const void* wt_dev, void* qkv_dev, int32_t M, int32_t H, int32_t hd,
+                                   int32_t K, const void* rope_dev, const int32_t* pos_dev, const int32_t* stream_dev,
+                                   void* kv_pool_dev, int64_t layer_stride_elems, int32_t layer,
+                                   const int32_t* block_table_dev, int32_t max_pages, void* stream) {
+    return op_qkv(false, a_dev, wt_dev, qkv_dev, M, H, hd, K, rope_dev, pos_dev, stream_dev, kv_pool_dev, layer_stride_elems,
+                  layer, block_table_dev, max_pages, stream);
+}
+extern "C" int t3_op_gemm_prompt_qkv_rope(const void* a_dev, const void* wt_dev, void* qkv_dev, int32_t M, int32_t H,
+                                          int32_t hd, int32_t K, const void* rope_dev, const int32_t* pos_dev,
+                                          const int32_t* stream_dev, void* kv_pool_dev, int64_t layer_stride_elems,
+                                          int32_t layer, const int32_t* block_table_dev, int32_t max_pages, void* stream) {
+    return op_qkv(true, a_dev, wt_dev, qkv_dev, M, H, hd, K, rope_dev, pos_dev, stream_dev, kv_pool_dev, layer_stride_elems,
+                  layer, block_table_dev, max_pages, stream);
 }
 
 extern "C" int t3_op_attn_decode(const void* qkv_dev, void* out_dev, int32_t rows, int32_t H, int32_t hd,

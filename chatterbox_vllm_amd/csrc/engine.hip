@@ -288,13 +288,15 @@ int run_layers(t3_engine* e, int rows, const int32_t* d_pos, const int32_t* d_st
     const KvView kv = e->kvview();
     for (int li = 0; li < c.n_layers; ++li) {
         const Layer& L = e->layers[li];
-        // o_proj / down_proj leave split-K partial slabs, folded in by the next norm kernel
+        // o_proj / down_proj leave split-K partial slabs, folded in by the next norm kernel.  Prompt rows always
+        // take the LDS-tiled kernels and decode rows the weight-streaming ones, whatever the row count, so that
+        // a row's bits never depend on what shares its launch.
         T3_RUN(e, K_NORM, li, 4LL * rows * D, launch_slab_add_rmsnorm(e->b->slab, li > 0 ? GEMM_SLAB_SPLIT : 0, e->b->res, L.ln1,
                                                                       e->b->xn, rows, D, c.rms_eps, st));
         GemmArgs g{};
         g.A = e->b->xn; g.lda = D; g.Wt = L.wqkv; g.C = e->b->qkv; g.ldc = 3 * D; g.M = rows; g.N = 3 * D; g.K = D;
         g.n_valid = 3 * D; g.rope = e->rope; g.pos = d_pos; g.row_stream = d_stream; g.kv = kv; g.layer = li;
-        T3_RUN(e, K_QKV, li, 2LL * 3 * D * D, launch_gemm(EPI_QKV_ROPE, g, st));
+        T3_RUN(e, K_QKV, li, 2LL * 3 * D * D, prefill ? launch_gemm_prompt(EPI_QKV_ROPE, g, st) : launch_gemm(EPI_QKV_ROPE, g, st));
         if (prefill) {
             T3_RUN(e, K_ATTN_PREFILL, li, 2LL * rows * 4 * D, launch_attn_prefill(e->b->qkv, 3 * D, e->b->att, d_seq_start, d_tiles, ntiles, H, hd, st));
         } else {
@@ -303,16 +305,16 @@ int run_layers(t3_engine* e, int rows, const int32_t* d_pos, const int32_t* d_st
         GemmArgs o{};
         o.A = e->b->att; o.lda = D; o.Wt = L.wo; o.C = e->b->res; o.ldc = D; o.M = rows; o.N = D; o.K = D; o.n_valid = D;
         o.slab = e->b->slab;
-        T3_RUN(e, K_OPROJ, li, 2LL * D * D, launch_gemm_slab(o, st));
+        T3_RUN(e, K_OPROJ, li, 2LL * D * D, prefill ? launch_gemm_prompt(EPI_SLAB, o, st) : launch_gemm_slab(o, st));
         T3_RUN(e, K_NORM, li, 4LL * rows * D, launch_slab_add_rmsnorm(e->b->slab, GEMM_SLAB_SPLIT, e->b->res, L.ln2, e->b->xn, rows, D,
                                                                       c.rms_eps, st));
         GemmArgs u{};
         u.A = e->b->xn; u.lda = D; u.Wt = L.wgu; u.C = e->b->hbuf; u.ldc = F; u.M = rows; u.N = 2 * F; u.K = D; u.n_valid = 2 * F;
-        T3_RUN(e, K_GATEUP, li, 2LL * 2 * F * D, launch_gemm(EPI_SILU, u, st));
+        T3_RUN(e, K_GATEUP, li, 2LL * 2 * F * D, prefill ? launch_gemm_prompt(EPI_SILU, u, st) : launch_gemm(EPI_SILU, u, st));
         GemmArgs dn{};
         dn.A = e->b->hbuf; dn.lda = F; dn.Wt = L.wd; dn.C = e->b->res; dn.ldc = D; dn.M = rows; dn.N = D; dn.K = F; dn.n_valid = D;
         dn.slab = e->b->slab;
-        T3_RUN(e, K_DOWN, li, 2LL * F * D, launch_gemm_slab(dn, st));
+        T3_RUN(e, K_DOWN, li, 2LL * F * D, prefill ? launch_gemm_prompt(EPI_SLAB, dn, st) : launch_gemm_slab(dn, st));
     }
     T3_RUN(e, K_NORM, -1, 4LL * rows * D, launch_slab_add_rmsnorm(e->b->slab, GEMM_SLAB_SPLIT, e->b->res, e->norm_w, e->b->xn, rows, D,
                                                                   c.rms_eps, st));

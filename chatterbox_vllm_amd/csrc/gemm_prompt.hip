@@ -1,0 +1,254 @@
+// Prompt-row GEMM for the T3 backbone on gfx950:  C[M,N] = A[M,K] * W[N,K]^T for the rows of a prefill
+// (M = a few hundred).  The weight-streaming kernel of gemm.hip makes every workgroup read all rows
+// of A for 32 output columns; at these M that is 250+ MB of L1 fill per launch.  Here a workgroup
+// owns a 128 x 128 output tile and walks K in steps of 64 through LDS, so A and W are each read
+// once per tile (L1 fill per launch = (M + N) * K * 2 * tiles-per-side, 4x less).
+//
+//   256 threads = 4 waves as 2 (rows) x 2 (columns); a wave accumulates 64 x 64 = 4 x 4 MFMA tiles
+//   (v_mfma_f32_16x16x32_bf16, W tile as the A operand so a lane ends up with 4 consecutive columns
+//   of one row, as in gemm.hip).
+//   LDS per stage: A 128 rows x 64 k, row-major with a 144-byte row stride (conflict-free 16-byte
+//   reads of 16 rows); W 8 n-blocks x 2 k-tiles in the global tile order (a lane's fragment is its
+//   own 16 bytes of a 1 KiB tile).  Two stages; the next stage's global loads are in flight in
+//   registers while the current one is multiplied.
+//   Workgroup -> tile: linear id b runs on XCD b % 8; each XCD takes a contiguous run of tiles in
+//   (split, column tile, row tile) order, so the row tiles that share a weight tile share an L2.
+//
+// K is accumulated in k order inside one accumulator (per split), whatever M is: a row's result does
+// not depend on the other rows of the launch.  It does differ in rounding from gemm.hip's 8-wave
+// K split, which is why the engine sends prompt rows here and decode rows there, always.
+//
+// Epilogues: EPI_QKV_ROPE (a wave's 64 columns are one head: RoPE pairs (c, c+32) sit in one lane;
+// q|k|v row store + KV-cache scatter), EPI_SILU (a workgroup takes 64 gate and the matching 64 up
+// columns), EPI_SLAB (split-K 8 fp32 partials for o_proj / down_proj, summed by the norm kernel).
+#include "t3_common.h"
+
+namespace {
+
+constexpr int PBM = 128, PBN = 128, PBK = 64;
+constexpr int PA_STRIDE = PBK + 8;                   // bf16 elements per LDS row of A (144 bytes)
+constexpr int PA_ELEMS = PBM * PA_STRIDE;            // 9216
+constexpr int PW_ELEMS = 8 * 2 * 512;                // 8 n-blocks x 2 k-tiles x 512 elements
+constexpr int PSTAGE = PA_ELEMS + PW_ELEMS;          // 17408 elements = 34816 bytes
+
+}  // namespace
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_prompt_kernel(GemmArgs a, int m_tiles, int n_tiles, int ksplit, int per_xcd) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t plds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w >> 1, wn = w & 1;
+
+    const int total = m_tiles * n_tiles * ksplit;
+    const int t = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (t >= total) return;
+    const int m_tile = t % m_tiles;
+    const int rest = t / m_tiles;
+    const int n_tile = rest % n_tiles;
+    const int z = rest / n_tiles;
+    const int m0 = m_tile * PBM;
+    const int ktiles = a.K >> 5;
+    const int kspan = a.K / ksplit;                   // K range of this workgroup
+    const int k0 = z * kspan;
+    const int nks = kspan / PBK;
+
+    // the 8 n-blocks (16 weight rows each) of this tile; wave wn multiplies slots wn*4 .. wn*4+3
+    int H = 0, region = 0, hp = 0;
+    if constexpr (EPI == EPI_QKV_ROPE) {
+        H = a.kv.H;
+        region = n_tile / (H >> 1);
+        hp = n_tile - region * (H >> 1);
+    }
+    auto nb_of = [&](int s) -> int {
+        const int wv = s >> 2, ni = s & 3;
+        if constexpr (EPI == EPI_SILU)                // slots 0,1 of a wave: gate; 2,3: the matching up rows (F/16 further)
+            return n_tile * 4 + wv * 2 + (ni & 1) + (ni >> 1) * (a.N >> 5);
+        else if constexpr (EPI == EPI_QKV_ROPE)       // a wave = one head: 4 n-blocks of 16 columns
+            return region * 4 * H + (2 * hp + wv) * 4 + ni;
+        else
+            return n_tile * 8 + s;
+    };
+
+    // global -> register staging: 4 x 16 B of A and 4 x 16 B of W per thread and k-step
+    const bf16_t* ag[4];
+    int a_lds[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = i * 32 + (tid >> 3), chunk = tid & 7;
+        int r = m0 + row;
+        r = r < a.M ? r : a.M - 1;
+        ag[i] = a.A + (size_t)r * a.lda + k0 + chunk * 8;
+        a_lds[i] = row * PA_STRIDE + chunk * 8;
+    }
+    const bf16_t* wg[4];
+    int w_lds[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = i * 256 + tid;                // 16-byte unit 0..1023 of the stage's W block
+        const int slot = idx >> 7, within = idx & 127;
+        wg[i] = a.Wt + ((size_t)nb_of(slot) * ktiles + (k0 >> 5)) * 512 + within * 8;
+        w_lds[i] = PA_ELEMS + idx * 8;
+    }
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    u32x4 ra[4], rw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const u32x4*>(ag[i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rw[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wg[i]));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(plds + a_lds[i]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(plds + w_lds[i]) = rw[i];
+    __syncthreads();
+
+    const int a_frag = (wm * 64 + (lane & 15)) * PA_STRIDE + 8 * (lane >> 4);
+    const int w_frag = PA_ELEMS + wn * 4 * 1024 + lane * 8;
+    for (int ks = 0; ks < nks; ++ks) {
+        const bf16_t* cur = plds + (ks & 1) * PSTAGE;
+        const bool more = ks + 1 < nks;
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const u32x4*>(ag[i] + (ks + 1) * PBK);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                rw[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wg[i] + (size_t)(ks + 1) * 1024));
+        }
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            bf16x8 af[4], wf[4];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+                af[mi] = *reinterpret_cast<const bf16x8*>(cur + a_frag + mi * 16 * PA_STRIDE + kt * 32);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+                wf[ni] = *reinterpret_cast<const bf16x8*>(cur + w_frag + ni * 1024 + kt * 512);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[mi][ni], 0, 0, 0);
+        }
+        if (more) {
+            bf16_t* nxt = plds + ((ks + 1) & 1) * PSTAGE;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(nxt + a_lds[i]) = ra[i];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(nxt + w_lds[i]) = rw[i];
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds columns 4*(lane>>4)..+3 of n-block `ni`, row (lane & 15) of row tile `mi`
+    const int nl = 4 * (lane >> 4);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int r = m0 + wm * 64 + mi * 16 + (lane & 15);
+        if (r >= a.M) continue;
+        if constexpr (EPI == EPI_SLAB) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+                *reinterpret_cast<f32x4*>(a.slab + ((size_t)z * a.M + r) * a.N + nb_of(wn * 4 + ni) * 16 + nl) = acc[mi][ni];
+        } else if constexpr (EPI == EPI_SILU) {
+            const int F = a.N >> 1;
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                float hv[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float g = rbf(acc[mi][ni][i]), u = rbf(acc[mi][ni + 2][i]);
+                    const float sg = rbf(g / (1.0f + expf(-g)));
+                    hv[i] = sg * u;
+                }
+                const u32x2 o = {pack_bf2(hv[0], hv[1]), pack_bf2(hv[2], hv[3])};
+                *reinterpret_cast<u32x2*>(a.C + (size_t)r * F + (n_tile * 4 + wn * 2 + ni) * 16 + nl) = o;
+            }
+        } else {   // EPI_QKV_ROPE: this wave's 64 columns are head `head` of q, k or v
+            const int hd = 64, D = H * hd;
+            const int head = 2 * hp + wn;
+            const int pos = a.pos[r];
+            bf16_t* qrow = a.C + (size_t)r * a.ldc + region * D + head * hd;
+            bf16_t* kvrow = nullptr;
+            if (region >= 1) {
+                const int st = a.row_stream[r];
+                if (st >= 0) {
+                    const int page = a.kv.block_table[(size_t)st * a.kv.max_pages + (pos >> 6)];
+                    kvrow = a.kv.pool + (size_t)a.layer * a.kv.layer_stride +
+                            ((size_t)page * 2 + (region - 1)) * ((size_t)H * T3_PAGE * hd) +
+                            ((size_t)head * T3_PAGE + (pos & 63)) * hd;
+                }
+            }
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const int c0 = ni * 16 + nl, c1 = c0 + 32;
+                float x[4], y[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { x[i] = rbf(acc[mi][ni][i]); y[i] = rbf(acc[mi][ni + 2][i]); }
+                if (region < 2) {
+                    const bf16_t* tb = a.rope + (size_t)pos * hd;
+                    const u32x2 cs = *reinterpret_cast<const u32x2*>(tb + c0);
+                    const u32x2 sn = *reinterpret_cast<const u32x2*>(tb + 32 + c0);
+                    const float c[4] = {bf_lo(cs[0]), bf_hi(cs[0]), bf_lo(cs[1]), bf_hi(cs[1])};
+                    const float sv[4] = {bf_lo(sn[0]), bf_hi(sn[0]), bf_lo(sn[1]), bf_hi(sn[1])};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float xr = x[i] * c[i] - y[i] * sv[i];
+                        const float yr = y[i] * c[i] + x[i] * sv[i];
+                        x[i] = xr; y[i] = yr;
+                    }
+                }
+                const u32x2 ox = {pack_bf2(x[0], x[1]), pack_bf2(x[2], x[3])};
+                const u32x2 oy = {pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3])};
+                *reinterpret_cast<u32x2*>(qrow + c0) = ox;
+                *reinterpret_cast<u32x2*>(qrow + c1) = oy;
+                if (kvrow) {
+                    *reinterpret_cast<u32x2*>(kvrow + c0) = ox;
+                    *reinterpret_cast<u32x2*>(kvrow + c1) = oy;
+                }
+            }
+        }
+    }
+}
+
+template <int EPI>
+static int launch_prompt(const GemmArgs& a, int n_tiles, int ksplit, hipStream_t st) {
+    constexpr size_t lds = 2 * (size_t)PSTAGE * sizeof(bf16_t);
+    static bool attr_set = false;
+    if (!attr_set) {
+        T3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_prompt_kernel<EPI>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const int m_tiles = (a.M + PBM - 1) / PBM;
+    const int total = m_tiles * n_tiles * ksplit;
+    const int per_xcd = (total + 7) / 8;
+    T3_LAUNCH((gemm_prompt_kernel<EPI>), dim3(per_xcd * 8), dim3(256), lds, st, a, m_tiles, n_tiles, ksplit, per_xcd);
+    T3_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_gemm_prompt(int epi, const GemmArgs& a, hipStream_t st) {
+    T3_REQUIRE(a.M >= 1 && a.lda % 8 == 0, "gemm_prompt: bad rows or lda");
+    T3_REQUIRE(a.K % (PBK * GEMM_SLAB_SPLIT) == 0, "gemm_prompt: K must be a multiple of 512");
+    switch (epi) {
+        case EPI_SILU:
+            T3_REQUIRE(a.N % 128 == 0, "gemm_prompt silu: N = 2F with F % 64 == 0");
+            return launch_prompt<EPI_SILU>(a, a.N / 128, 1, st);   // a tile = 64 gate + the matching 64 up columns
+        case EPI_QKV_ROPE:
+            T3_REQUIRE(a.kv.hd == 64 && a.kv.H % 2 == 0 && a.N == 3 * a.kv.H * 64 && a.ldc % 4 == 0,
+                       "gemm_prompt qkv: needs head_dim 64, an even head count, N = 3*H*64");
+            return launch_prompt<EPI_QKV_ROPE>(a, a.N / PBN, 1, st);
+        case EPI_SLAB:
+            T3_REQUIRE(a.slab != nullptr && a.N % PBN == 0, "gemm_prompt slab: N must be a multiple of 128");
+            return launch_prompt<EPI_SLAB>(a, a.N / PBN, GEMM_SLAB_SPLIT, st);
+    }
+    t3_set_error("gemm_prompt: unknown epilogue");
+    return 1;
+}

@@ -102,6 +102,8 @@ struct GemmArgs {
 #endif
 int launch_gemm(int epi, const GemmArgs& a, hipStream_t st);
 int launch_gemm_slab(const GemmArgs& a, hipStream_t st);
+// Prompt rows (prefill): LDS-tiled 128 x 128 kernel, epi = EPI_QKV_ROPE, EPI_SILU or EPI_SLAB (split-K 8).
+int launch_gemm_prompt(int epi, const GemmArgs& a, hipStream_t st);
 // res = bf16(bf16(sum_s slab[s]) + res) when slab != nullptr (nsplit slabs of [rows, d] fp32);
 // xn = rmsnorm(res) * w.  One pass, the row stays in registers.
 int launch_slab_add_rmsnorm(const float* slab, int nsplit, bf16_t* res, const bf16_t* w, bf16_t* xn, int rows, int d,

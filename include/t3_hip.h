@@ -157,6 +157,18 @@ int t3_op_gemm_qkv_rope(const void* a_dev, const void* wt_dev, void* qkv_dev, in
                         int32_t K, const void* rope_dev, const int32_t* pos_dev, const int32_t* stream_dev,
                         void* kv_pool_dev, int64_t layer_stride_elems, int32_t layer,
                         const int32_t* block_table_dev, int32_t max_pages, void* stream);
+/* Prompt-row forms of the three fused projections above (same arguments, same arithmetic contract):
+ * an LDS-tiled 128 x 128 kernel for the few hundred rows of a prefill, where the weight-streaming
+ * kernels would re-read every activation row once per 32 output columns.  The engine sends prompt
+ * rows here and decode rows to the forms above, always, so a row's bits do not depend on the launch. */
+int t3_op_gemm_prompt_slab(const void* a_dev, const void* wt_dev, float* slab_dev, int32_t M, int32_t N, int32_t K,
+                           void* stream);
+int t3_op_gemm_prompt_silu(const void* a_dev, const void* wt_dev, void* h_dev, int32_t M, int32_t F, int32_t K,
+                           void* stream);
+int t3_op_gemm_prompt_qkv_rope(const void* a_dev, const void* wt_dev, void* qkv_dev, int32_t M, int32_t H, int32_t hd,
+                               int32_t K, const void* rope_dev, const int32_t* pos_dev, const int32_t* stream_dev,
+                               void* kv_pool_dev, int64_t layer_stride_elems, int32_t layer,
+                               const int32_t* block_table_dev, int32_t max_pages, void* stream);
 /* Single-query attention over the paged KV cache: row r attends to positions
  * [0, ctx_dev[r]) of KV stream stream_dev[r]; q is read from qkv_dev[r, 0:H*hd]. */
 int t3_op_attn_decode(const void* qkv_dev, void* out_dev, int32_t rows, int32_t H, int32_t hd,

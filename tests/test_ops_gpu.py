@@ -76,14 +76,19 @@ def test_gemm_rows_do_not_depend_on_batch(capi):
         assert torch.equal(part, full[:M]), f"rows change with M={M}"
 
 
-@pytest.mark.parametrize("M", [1, 20, 64, 130])
-def test_gemm_silu(capi, M):
+# the weight-streaming (decode) and the LDS-tiled (prompt rows) form of each fused projection
+FORMS = ["t3_op_gemm", "t3_op_gemm_prompt"]
+
+
+@pytest.mark.parametrize("form", FORMS)
+@pytest.mark.parametrize("M", [1, 20, 64, 130, 400])
+def test_gemm_silu(capi, M, form):
     K, F = 1024, 4096
     a = _rand((M, K), 8).to(DEV)
     w = _rand((2 * F, K), 9, 0.05).to(DEV)
     wt = repack(capi, w)
     h = torch.zeros(M, F, dtype=torch.bfloat16, device=DEV)
-    call(capi, "t3_op_gemm_silu", p(a), p(wt), p(h), M, F, K, None)
+    call(capi, form + "_silu", p(a), p(wt), p(h), M, F, K, None)
     torch.cuda.synchronize()
     gu = r16(a.float() @ w.float().T)
     g, u = gu[:, :F], gu[:, F:]
@@ -101,8 +106,9 @@ def _kv_setup(n_streams, max_pages, n_layers, H=16, hd=64, seed=0):
     return pool, bt, n_pages * page_elems
 
 
-@pytest.mark.parametrize("M", [1, 19, 64, 150])
-def test_gemm_qkv_rope_and_cache_write(capi, M):
+@pytest.mark.parametrize("form", FORMS)
+@pytest.mark.parametrize("M", [1, 19, 64, 150, 389])
+def test_gemm_qkv_rope_and_cache_write(capi, M, form):
     cfg = T3ModelConfig.english()
     H, hd, K = 16, 64, 1024
     a = _rand((M, K), 10).to(DEV)
@@ -122,7 +128,7 @@ def test_gemm_qkv_rope_and_cache_write(capi, M):
         stream[2] = -1                                   # a row that must not touch the cache
     qkv = torch.zeros(M, 3 * H * hd, dtype=torch.bfloat16, device=DEV)
     btd, posd, std = bt.to(DEV), pos.to(DEV), stream.to(DEV)
-    call(capi, "t3_op_gemm_qkv_rope", p(a), p(wt), p(qkv), M, H, hd, K, p(rope), p(posd), p(std), p(pool),
+    call(capi, form + "_qkv_rope", p(a), p(wt), p(qkv), M, H, hd, K, p(rope), p(posd), p(std), p(pool),
          layer_stride, 1, p(btd), max_pages, None)
     torch.cuda.synchronize()
     ref = r16(a.float() @ w.float().T).cpu()
@@ -291,9 +297,10 @@ def test_sampler_cfg_penalty_argmax_is_exact(capi):
     assert int(toks[0]) == 1077
 
 
-@pytest.mark.parametrize("M", [1, 30, 64, 100])
+@pytest.mark.parametrize("form", FORMS)
+@pytest.mark.parametrize("M", [1, 30, 64, 100, 300])
 @pytest.mark.parametrize("K", [1024, 4096])
-def test_split_k_slabs_then_residual_norm(capi, M, K):
+def test_split_k_slabs_then_residual_norm(capi, M, K, form):
     """Decode-path pair: t3_op_gemm_slab leaves fp32 partial sums, t3_op_slab_add_rmsnorm folds them
     into the residual stream and normalises.  Equals gemm + residual add + rmsnorm of the contract."""
     N = 1024
@@ -302,7 +309,7 @@ def test_split_k_slabs_then_residual_norm(capi, M, K):
     w = _rand((N, K), 71, 0.02).to(DEV)
     wt = repack(capi, w)
     slab = torch.full((S, M, N), float("nan"), device=DEV)
-    call(capi, "t3_op_gemm_slab", p(a), p(wt), p(slab), M, N, K, None)
+    call(capi, form + "_slab", p(a), p(wt), p(slab), M, N, K, None)
     torch.cuda.synchronize()
     ref = a.float() @ w.float().T
     assert torch.isfinite(slab).all()
@@ -323,7 +330,7 @@ def test_split_k_slabs_then_residual_norm(capi, M, K):
     if M > 1:
         slab1 = torch.zeros(S, 1, N, device=DEV)
         a1 = a[:1].contiguous()
-        call(capi, "t3_op_gemm_slab", p(a1), p(wt), p(slab1), 1, N, K, None)
+        call(capi, form + "_slab", p(a1), p(wt), p(slab1), 1, N, K, None)
         torch.cuda.synchronize()
         assert torch.equal(slab1[:, 0], slab[:, 0])
     # nsplit == 0 leaves the residual alone

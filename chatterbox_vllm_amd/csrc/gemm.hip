@@ -288,6 +288,9 @@ int launch_gemm(int epi, const GemmArgs& a, hipStream_t st) {
         case EPI_QKV_ROPE:
             T3_REQUIRE(a.K == 1024 && a.kv.hd == 64 && a.N == 3 * a.kv.H * 64, "gemm_qkv: needs K=1024, head_dim 64");
             T3_REQUIRE(a.ldc % 4 == 0, "gemm_qkv: ldc must be a multiple of 4");
+            // only 96 column pairs: above 32 rows, row groups of 32 put twice the workgroups to work, each
+            // reading half the activations (the groups of one column pair share an XCD, hence its L2 copy of W)
+            if (a.M > 32) return launch_one<2, 2, 8, 4, EPI_QKV_ROPE>(a, a.N / 32, st);
             return launch_mt<2, 8, 4, EPI_QKV_ROPE>(a, a.N / 32, st);
     }
     t3_set_error("gemm: unknown epilogue");

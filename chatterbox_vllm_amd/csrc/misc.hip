@@ -64,50 +64,73 @@ __global__ __launch_bounds__(128) void add_rmsnorm_kernel(const bf16_t* __restri
 // sum of squares and the scaling, and the split-K partial sums of the preceding projection
 // are folded in first:  res = bf16(bf16(slab[0] + slab[1] + ... ) + res)  in slab order.
 // ------------------------------------------------------------------------------------
+#define SLAB_NORM_THREADS 128      // 256 threads (4 elements each) measured the same: the kernel is one memory round trip
 template <int NSPLIT>
-__global__ __launch_bounds__(128) void slab_add_rmsnorm_kernel(const float* __restrict__ slab,
+__global__ __launch_bounds__(SLAB_NORM_THREADS) void slab_add_rmsnorm_kernel(const float* __restrict__ slab,
                                                                size_t slab_stride, bf16_t* __restrict__ res,
                                                                const bf16_t* __restrict__ w, bf16_t* __restrict__ xn,
                                                                float eps) {
     constexpr int d = 1024;
-    __shared__ float part[2];
+    constexpr int NT = SLAB_NORM_THREADS, EPT = d / NT, NV = EPT / 4;   // elements per thread, fp32x4 pieces per thread
+    __shared__ float part[NT / 64];
     const size_t row = blockIdx.x;
-    const int tid = threadIdx.x, c = tid * 8;
-    const u32x4 rv = *reinterpret_cast<const u32x4*>(res + row * d + c);
-    const u32x4 wv = *reinterpret_cast<const u32x4*>(w + c);
-    float z[8];
+    const int tid = threadIdx.x, c = tid * EPT;
+    float z[EPT], wz[EPT];
+    if constexpr (EPT == 8) {
+        const u32x4 rv = *reinterpret_cast<const u32x4*>(res + row * d + c);
+        const u32x4 wv = *reinterpret_cast<const u32x4*>(w + c);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { z[2 * i] = bf_lo(rv[i]); z[2 * i + 1] = bf_hi(rv[i]); }
+        for (int i = 0; i < 4; ++i) { z[2 * i] = bf_lo(rv[i]); z[2 * i + 1] = bf_hi(rv[i]); wz[2 * i] = bf_lo(wv[i]); wz[2 * i + 1] = bf_hi(wv[i]); }
+    } else {
+        const u32x2 rv = *reinterpret_cast<const u32x2*>(res + row * d + c);
+        const u32x2 wv = *reinterpret_cast<const u32x2*>(w + c);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { z[2 * i] = bf_lo(rv[i]); z[2 * i + 1] = bf_hi(rv[i]); wz[2 * i] = bf_lo(wv[i]); wz[2 * i + 1] = bf_hi(wv[i]); }
+    }
     if constexpr (NSPLIT > 0) {
         const float* sp = slab + row * d + c;
-        f32x4 p0[NSPLIT], p1[NSPLIT];                      // all partial loads in flight at once
+        f32x4 p[NSPLIT][NV];                               // all partial loads in flight at once
 #pragma unroll
-        for (int s = 0; s < NSPLIT; ++s) {
-            p0[s] = *reinterpret_cast<const f32x4*>(sp + s * slab_stride);
-            p1[s] = *reinterpret_cast<const f32x4*>(sp + s * slab_stride + 4);
+        for (int s = 0; s < NSPLIT; ++s)
+#pragma unroll
+            for (int v = 0; v < NV; ++v) p[s][v] = *reinterpret_cast<const f32x4*>(sp + s * slab_stride + 4 * v);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            f32x4 a = p[0][v];
+#pragma unroll
+            for (int s = 1; s < NSPLIT; ++s) a += p[s][v];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) z[4 * v + i] = rbf(rbf(a[i]) + z[4 * v + i]);
         }
-        f32x4 a0 = p0[0], a1 = p1[0];
+        if constexpr (EPT == 8) {
+            u32x4 o;
 #pragma unroll
-        for (int s = 1; s < NSPLIT; ++s) { a0 += p0[s]; a1 += p1[s]; }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { z[i] = rbf(rbf(a0[i]) + z[i]); z[4 + i] = rbf(rbf(a1[i]) + z[4 + i]); }
-        u32x4 o;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = pack_bf2(z[2 * i], z[2 * i + 1]);
-        *reinterpret_cast<u32x4*>(res + row * d + c) = o;
+            for (int i = 0; i < 4; ++i) o[i] = pack_bf2(z[2 * i], z[2 * i + 1]);
+            *reinterpret_cast<u32x4*>(res + row * d + c) = o;
+        } else {
+            const u32x2 o = {pack_bf2(z[0], z[1]), pack_bf2(z[2], z[3])};
+            *reinterpret_cast<u32x2*>(res + row * d + c) = o;
+        }
     }
     float ss = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) ss += z[i] * z[i];
+    for (int i = 0; i < EPT; ++i) ss += z[i] * z[i];
     ss = wave_sum(ss);
     if ((tid & 63) == 0) part[tid >> 6] = ss;
     __syncthreads();
-    const float sc = 1.0f / sqrtf((part[0] + part[1]) / (float)d + eps);
-    u32x4 o;
+    float tot = part[0];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-        o[i] = pack_bf2(rbf(z[2 * i] * sc) * bf_lo(wv[i]), rbf(z[2 * i + 1] * sc) * bf_hi(wv[i]));
-    *reinterpret_cast<u32x4*>(xn + row * d + c) = o;
+    for (int k = 1; k < NT / 64; ++k) tot += part[k];
+    const float sc = 1.0f / sqrtf(tot / (float)d + eps);
+    if constexpr (EPT == 8) {
+        u32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = pack_bf2(rbf(z[2 * i] * sc) * wz[2 * i], rbf(z[2 * i + 1] * sc) * wz[2 * i + 1]);
+        *reinterpret_cast<u32x4*>(xn + row * d + c) = o;
+    } else {
+        const u32x2 o = {pack_bf2(rbf(z[0] * sc) * wz[0], rbf(z[1] * sc) * wz[1]), pack_bf2(rbf(z[2] * sc) * wz[2], rbf(z[3] * sc) * wz[3])};
+        *reinterpret_cast<u32x2*>(xn + row * d + c) = o;
+    }
 }
 
 int launch_slab_add_rmsnorm(const float* slab, int nsplit, bf16_t* res, const bf16_t* w, bf16_t* xn, int rows, int d,
@@ -115,9 +138,9 @@ int launch_slab_add_rmsnorm(const float* slab, int nsplit, bf16_t* res, const bf
     T3_REQUIRE(rows >= 1 && d == 1024, "slab_add_rmsnorm: d must be 1024");
     T3_REQUIRE(nsplit == 0 || (slab != nullptr && nsplit == GEMM_SLAB_SPLIT), "slab_add_rmsnorm: nsplit must be 0 or the split count");
     if (nsplit == 0)
-        T3_LAUNCH(slab_add_rmsnorm_kernel<0>, dim3(rows), dim3(128), 0, st, slab, (size_t)rows * d, res, w, xn, eps);
+        T3_LAUNCH(slab_add_rmsnorm_kernel<0>, dim3(rows), dim3(SLAB_NORM_THREADS), 0, st, slab, (size_t)rows * d, res, w, xn, eps);
     else
-        T3_LAUNCH(slab_add_rmsnorm_kernel<GEMM_SLAB_SPLIT>, dim3(rows), dim3(128), 0, st, slab, (size_t)rows * d, res, w, xn, eps);
+        T3_LAUNCH(slab_add_rmsnorm_kernel<GEMM_SLAB_SPLIT>, dim3(rows), dim3(SLAB_NORM_THREADS), 0, st, slab, (size_t)rows * d, res, w, xn, eps);
     T3_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -15,6 +15,13 @@ the README-implied mean of 394 tokens.  Each rank runs the same job on its own G
 scaling: requests are independent; the only collective is the final all-gather of ids); value =
 tokens of all ranks / max-over-ranks time.
 
+Other configurations of the same engine (not the driver's default line; results are quoted in DESIGN.md):
+  --workload single         one request, CFG off (one KV stream), 152 text ids, decoded to position 1000
+  --workload multilingual   multilingual vocabulary (2454), fr + zh chunk lengths of the reference's
+                            benchmark-multilingual-{fr,zh}.py mixed in one queue, 4 voices; use --concurrency 64
+  --quantization int8       W8A16 backbone weights; with --concurrency 128 --repeat-job 2 the int8 / batch-128 case
+                            (under torchrun the 128 slots are divided over the ranks)
+
 Besides the throughput line this prints, in the same JSON object:
   roofline      the dominant kernel's algorithmic bytes / its HIP-event time, measured in a
                 separate pass over the same job with every launch bracketed by events
@@ -43,31 +50,49 @@ CFG_SCALE = 3.0
 MEAN_OUT = 394                 # README-implied mean speech tokens per chunk (4577.88 tok/s * 13.25 s / 154)
 
 
-def build_job(seed: int, n_requests: int = 0):
-    """(text_ids, out_len) per request of the 154-chunk job."""
+def _fixture():
     with open(os.path.join(ROOT, "tests", "golden", "ref_text_fixture.json")) as f:
-        lens = json.load(f)["benchmark_text_1"]["text_id_counts"]
-    if n_requests:
-        lens = lens[:n_requests]
-    mean_t = sum(lens) / len(lens)
+        return json.load(f)
+
+
+def build_job(seed: int, n_requests: int = 0, workload: str = "benchmark", repeat: int = 1):
+    """(text_ids, out_len, voice) per request.  Output length ~ text length, mean MEAN_OUT at the English
+    job's mean text length, capped by max_model_len."""
+    fx = _fixture()
+    en_lens = fx["benchmark_text_1"]["text_id_counts"]
+    mean_t = sum(en_lens) / len(en_lens)
     g = torch.Generator().manual_seed(seed)
+    if workload == "single":
+        spec = [(152, 255, 704, 0)]                        # (text ids, first id, vocab, voice)
+    elif workload == "multilingual":
+        fr = [(T, 634, 2454) for T in fx["benchmark_text_fr_1"]["text_id_counts"]]     # [fr] tag first (mtl_tokenizer.py:370)
+        zh = [(T, 725, 2454) for T in fx["benchmark_text_zh_1"]["text_id_counts"]]     # [zh]
+        mixed = [x for pair in zip(fr * 2, zh) for x in pair] + zh[len(fr) * 2:]
+        mixed = (mixed * (128 // len(mixed) + 1))[:128]
+        spec = [(T, first, vocab, i % 4) for i, (T, first, vocab) in enumerate(mixed)]
+    else:
+        spec = [(T, 255, 704, 0) for T in en_lens]
+    spec = spec * repeat
+    if n_requests:
+        spec = spec[:n_requests]
     job = []
-    for T in lens:
-        body = torch.randint(3, 704, (T - 2,), generator=g).tolist()
-        text = [255] + body + [0]                       # [START] ... [STOP]
+    for T, first, vocab, voice in spec:
+        T = max(T, 3)
+        body = torch.randint(3, vocab, (T - 2,), generator=g).tolist()
+        text = [first] + body + [0]                     # [START] or language tag ... [STOP]
         P = 34 + T + 1
-        out = int(round(MEAN_OUT * T / mean_t))
+        out = MAX_MODEL_LEN - P if workload == "single" else int(round(MEAN_OUT * T / mean_t))
         out = max(16, min(out, MAX_MODEL_LEN - P))
-        job.append((text, out))
+        job.append((text, out, voice))
     return job
 
 
-def run_job(eng: T3Engine, job, cond, stats=None):
+def run_job(eng: T3Engine, job, conds, stats=None):
     """Queue the whole job and run the engine dry.  Returns (#tokens, ids per request)."""
     rids = []
-    for text, out_len in job:
+    for text, out_len, voice in job:
         sp = SamplingParams(temperature=0.0, repetition_penalty=2.0, max_tokens=out_len, stop_token_ids=None)
-        rids.append(eng.add_request(text, cond, sp))
+        rids.append(eng.add_request(text, conds[voice], sp))
     ids = {r: [] for r in rids}
     n = 0
     while eng.has_unfinished():
@@ -83,20 +108,21 @@ def run_job(eng: T3Engine, job, cond, stats=None):
     return n, [ids[r] for r in rids]
 
 
-def cpu_baseline(cfg, sd, job, cond):
+def cpu_baseline(cfg, sd, job, conds, paired=True):
     """The oracle on a bounded slice: 8 requests of the job (the 8 shortest texts), CFG-paired,
     prefill + 40 greedy tokens each, batched decode steps (10-30 s of CPU work)."""
     from oracle.t3_oracle import T3Oracle
     torch.set_num_threads(max(1, min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))))
     o = T3Oracle(sd, n_layers=cfg.n_layers, cfg_scale=CFG_SCALE)
     sub = sorted(job, key=lambda t: len(t[0]))[:8]
-    reqs = [(t, cond) for t, _ in sub]
+    reqs = [(t, conds[v]) for t, _, v in sub]
     t0 = time.time()
-    out = o.generate_batch(reqs, [40] * len(reqs))
+    out = o.generate_batch(reqs, [40] * len(reqs), paired=paired)
     dt = time.time() - t0
     ntok = sum(len(x) for x in out)
     return {"value": round(ntok / dt, 3), "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{len(reqs)} shortest requests of the job (text ids {[len(t) for t, _ in sub]}), CFG-paired, "
+            "sample": f"{len(reqs)} shortest requests of the job (text ids {[len(t) for t, _, _ in sub]}), "
+                      f"{'CFG-paired' if paired else 'single stream'}, "
                       f"prefill + 40 greedy tokens each, batched decode, {dt:.1f} s of CPU time"}, out, sub
 
 
@@ -119,6 +145,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--requests", type=int, default=0, help="use only the first N requests of the job (debug)")
     ap.add_argument("--layers", type=int, default=30, help="debug only: anything but 30 is not the benchmark")
+    ap.add_argument("--workload", choices=["benchmark", "single", "multilingual"], default="benchmark")
+    ap.add_argument("--concurrency", type=int, default=0, help="requests decoded together per job (default 32; single: 1)")
+    ap.add_argument("--quantization", choices=["none", "int8"], default="none")
+    ap.add_argument("--repeat-job", type=int, default=1, help="queue the request list this many times per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -134,16 +164,22 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    cfg = T3ModelConfig.english(n_layers=args.layers)
+    single = args.workload == "single"
+    paired = not single
+    conc = args.concurrency or (1 if single else CONCURRENCY)
+    if args.concurrency and world > 1 and args.quantization == "int8":
+        conc = max(1, args.concurrency // world)           # the int8 case divides its slots over the ranks
+    cfg = (T3ModelConfig.multilingual if args.workload == "multilingual" else T3ModelConfig.english)(n_layers=args.layers)
     sd = W.synthetic_state_dict(cfg, seed=1234)
     if dist is not None:
         # rank 0's checkpoint is the checkpoint: one RCCL broadcast of the weights over xGMI
         from chatterbox_vllm_amd.sharding import broadcast_state_dict
         sd = broadcast_state_dict(sd, src=0, device=torch.device("cuda", local_rank))
-    cond = W.synthetic_cond_emb(0)
-    job = build_job(seed=7 + rank, n_requests=args.requests)
-    eng = T3Engine(cfg, sd, max_model_len=MAX_MODEL_LEN, max_num_seqs=CONCURRENCY, cfg_scale=CFG_SCALE,
-                   cfg_paired=True, device=local_rank, max_prefill_rows=2048)
+    conds = [W.synthetic_cond_emb(v) for v in range(4)]
+    job = build_job(seed=7 + rank, n_requests=args.requests, workload=args.workload, repeat=args.repeat_job)
+    eng = T3Engine(cfg, sd, max_model_len=MAX_MODEL_LEN, max_num_seqs=conc, cfg_scale=CFG_SCALE,
+                   cfg_paired=paired, device=local_rank, max_prefill_rows=2048,
+                   quantization=None if args.quantization == "none" else args.quantization)
 
     def barrier():
         if dist is not None:
@@ -151,14 +187,14 @@ def main():
         torch.cuda.synchronize(local_rank)
 
     for _ in range(args.warmup):
-        run_job(eng, job, cond)
+        run_job(eng, job, conds)
     stats = {"decode_steps": 0, "decode_rows": 0, "decode_ctx_tokens": 0}
     barrier()
     t0 = time.perf_counter()
     tokens = 0
     last_ids = None
     for _ in range(args.steps):
-        n, last_ids = run_job(eng, job, cond, stats)
+        n, last_ids = run_job(eng, job, conds, stats)
         tokens += n
     barrier()
     dt = time.perf_counter() - t0
@@ -182,11 +218,17 @@ def main():
             "metric": METRIC, "value": round(total_tokens / dt, 2), "unit": "tokens/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "benchmark.py 154-chunk job (docs/benchmark-text-1.txt length histogram), "
-                                   "32 concurrent requests, CFG-paired scale 3.0, greedy, max_model_len 1000, "
-                                   f"output length ~ text length with mean {MEAN_OUT}; per GPU",
+            "config": {"workload": {
+                "benchmark": "benchmark.py 154-chunk job (docs/benchmark-text-1.txt length histogram), "
+                             f"{conc} concurrent requests, CFG-paired scale 3.0, greedy, max_model_len 1000, "
+                             f"output length ~ text length with mean {MEAN_OUT}; per GPU",
+                "single": "one request, CFG off (single KV stream), 152 text ids, greedy, decoded to position 1000",
+                "multilingual": "multilingual vocabulary 2454, fr + zh chunk lengths of benchmark-multilingual-{fr,zh}.py "
+                                f"mixed in one queue of 128 requests, 4 voices, {conc} concurrent requests, CFG-paired "
+                                "scale 3.0, greedy, max_model_len 1000; per GPU"}[args.workload],
                        "requests_per_gpu": len(job), "tokens_per_step_per_gpu": tokens // max(1, args.steps),
-                       "concurrency": CONCURRENCY, "layers": cfg.n_layers, "parallelism": f"request-sharded x{world}"},
+                       "concurrency": conc, "layers": cfg.n_layers, "weights": "int8 (W8A16)" if args.quantization == "int8" else "bf16",
+                       "parallelism": f"request-sharded x{world}"},
             "per_gpu_tokens_per_s": round(total_tokens / dt / world, 2),
             "decode": {"steps": stats["decode_steps"],
                        "mean_rows": round(stats["decode_rows"] / max(1, stats["decode_steps"]), 2),
@@ -197,7 +239,7 @@ def main():
     if rank == 0 and not args.no_roofline:
         eng.set_kernel_timing(True)
         t1 = time.perf_counter()
-        run_job(eng, job, cond)
+        run_job(eng, job, conds)
         timed_pass = time.perf_counter() - t1
         kd, kp = eng.kernel_times("decode"), eng.kernel_times("prefill")
         eng.set_kernel_timing(False)
@@ -225,7 +267,7 @@ def main():
     eng.shutdown()
 
     if rank == 0 and not args.no_cpu_baseline:
-        cb, cpu_ids, sub = cpu_baseline(cfg, sd, job, cond)
+        cb, cpu_ids, sub = cpu_baseline(cfg, sd, job, conds, paired=paired)
         result["cpu_baseline"] = cb
     if rank == 0:
         print(json.dumps(result))

@@ -24,7 +24,7 @@ class T3Config(C.Structure):
         ("d_ff", C.c_int32), ("text_vocab", C.c_int32), ("speech_vocab", C.c_int32),
         ("text_pos_rows", C.c_int32), ("speech_pos_rows", C.c_int32), ("max_model_len", C.c_int32),
         ("max_num_seqs", C.c_int32), ("cfg_paired", C.c_int32), ("max_prefill_rows", C.c_int32),
-        ("device", C.c_int32), ("use_graphs", C.c_int32), ("reserved0", C.c_int32),
+        ("device", C.c_int32), ("use_graphs", C.c_int32), ("weight_int8", C.c_int32),
         ("cfg_scale", C.c_float), ("rms_eps", C.c_float), ("kv_pages", C.c_int64),
     ]
 
@@ -48,6 +48,19 @@ class T3StepStats(C.Structure):
 
 _P = C.c_void_p
 _I32P = C.POINTER(C.c_int32)
+
+
+class T3GemmDesc(C.Structure):
+    _fields_ = [
+        ("a_dev", C.c_void_p), ("w_dev", C.c_void_p), ("w_scale_dev", C.c_void_p), ("out_dev", C.c_void_p),
+        ("slab_dev", C.c_void_p),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("ldc", C.c_int32),
+        ("epilogue", C.c_int32), ("prompt_form", C.c_int32),
+        ("H", C.c_int32), ("hd", C.c_int32), ("layer", C.c_int32), ("max_pages", C.c_int32),
+        ("rope_dev", C.c_void_p), ("pos_dev", C.c_void_p), ("stream_dev", C.c_void_p), ("kv_pool_dev", C.c_void_p),
+        ("layer_stride_elems", C.c_int64), ("block_table_dev", C.c_void_p),
+    ]
+
 
 # name -> (argtypes, restype); every symbol include/t3_hip.h declares
 SIGNATURES = {
@@ -83,6 +96,8 @@ SIGNATURES = {
     "t3_op_gemm_prompt_silu": ([_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P], C.c_int),
     "t3_op_gemm_prompt_qkv_rope": ([_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int64,
                                     C.c_int32, _P, C.c_int32, _P], C.c_int),
+    "t3_op_quantize_weight": ([_P, _P, _P, C.c_int32, C.c_int32, _P], C.c_int),
+    "t3_op_gemm_ex": ([C.POINTER(T3GemmDesc), _P], C.c_int),
     "t3_op_attn_decode": ([_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, C.c_int64, C.c_int32, _P,
                            C.c_int32, _P], C.c_int),
     "t3_op_attn_prefill": ([_P, _P, C.c_int32, _P, _I32P, C.c_int32, C.c_int32, _P], C.c_int),

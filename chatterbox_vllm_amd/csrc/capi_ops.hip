@@ -108,6 +108,45 @@ extern "C" int t3_op_gemm_prompt_qkv_rope(const void* a_dev, const void* wt_dev,
                   layer, block_table_dev, max_pages, stream);
 }
 
+extern "C" int t3_op_quantize_weight(const void* w_dev, void* wq_dev, float* scale_dev, int32_t N, int32_t K, void* stream) {
+    T3_REQUIRE(w_dev && wq_dev && scale_dev, "null argument");
+    return launch_quantize(static_cast<const bf16_t*>(w_dev), static_cast<uint8_t*>(wq_dev), scale_dev, N, K,
+                           static_cast<hipStream_t>(stream));
+}
+
+extern "C" int t3_op_gemm_ex(const t3_gemm_desc* d, void* stream) {
+    T3_REQUIRE(d && d->a_dev && d->w_dev, "null argument");
+    T3_REQUIRE(d->epilogue >= 0 && d->epilogue <= 4, "epilogue must be 0..4");
+    T3_REQUIRE(!d->prompt_form || d->epilogue >= 2, "the prompt form exists for epilogues 2, 3 and 4");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    GemmArgs g{};
+    g.A = static_cast<const bf16_t*>(d->a_dev); g.lda = d->K; g.Wt = static_cast<const bf16_t*>(d->w_dev);
+    g.wscale = d->w_scale_dev; g.C = static_cast<bf16_t*>(d->out_dev); g.M = d->M; g.N = d->N; g.K = d->K;
+    g.slab = d->slab_dev;
+    switch (d->epilogue) {
+        case 0: case 1:
+            T3_REQUIRE(d->out_dev && d->ldc >= 1, "bad output");
+            g.ldc = d->ldc; g.n_valid = d->ldc < d->N ? d->ldc : d->N;
+            return launch_gemm(d->epilogue == 0 ? EPI_STORE : EPI_RESID, g, st);
+        case 2:
+            T3_REQUIRE(d->out_dev, "bad output");
+            g.ldc = d->N / 2; g.n_valid = d->N;
+            return d->prompt_form ? launch_gemm_prompt(EPI_SILU, g, st) : launch_gemm(EPI_SILU, g, st);
+        case 3:
+            T3_REQUIRE(d->out_dev && d->rope_dev && d->pos_dev && d->stream_dev && d->kv_pool_dev && d->block_table_dev,
+                       "null argument");
+            T3_REQUIRE(d->N == 3 * d->H * d->hd, "N must be 3*H*hd");
+            g.ldc = d->N; g.n_valid = d->N; g.rope = static_cast<const bf16_t*>(d->rope_dev); g.pos = d->pos_dev;
+            g.row_stream = d->stream_dev; g.layer = d->layer;
+            g.kv = make_kv(d->kv_pool_dev, d->layer_stride_elems, d->block_table_dev, d->max_pages, d->H, d->hd);
+            return d->prompt_form ? launch_gemm_prompt(EPI_QKV_ROPE, g, st) : launch_gemm(EPI_QKV_ROPE, g, st);
+        default:
+            T3_REQUIRE(d->slab_dev, "null slab");
+            g.n_valid = d->N;
+            return d->prompt_form ? launch_gemm_prompt(EPI_SLAB, g, st) : launch_gemm_slab(g, st);
+    }
+}
+
 extern "C" int t3_op_attn_decode(const void* qkv_dev, void* out_dev, int32_t rows, int32_t H, int32_t hd,
                                  const int32_t* stream_dev, const int32_t* ctx_dev, const void* kv_pool_dev,
                                  int64_t layer_stride_elems, int32_t layer, const int32_t* block_table_dev,

@@ -71,6 +71,7 @@ struct Request {
 
 struct Layer {
     bf16_t *ln1 = nullptr, *ln2 = nullptr, *wqkv = nullptr, *wo = nullptr, *wgu = nullptr, *wd = nullptr;
+    float *sqkv = nullptr, *so = nullptr, *sgu = nullptr, *sd = nullptr;   // int8 weights: per-column scales
 };
 
 // kernel classes for the per-launch event timing mode
@@ -286,6 +287,7 @@ int run_layers(t3_engine* e, int rows, const int32_t* d_pos, const int32_t* d_st
     const int D = c.d_model, F = c.d_ff, H = c.n_heads, hd = c.head_dim;
     hipStream_t st = e->stream;
     const KvView kv = e->kvview();
+    const long long WB = c.weight_int8 ? 1 : 2;          // bytes per projection weight (algorithmic-bytes accounting)
     for (int li = 0; li < c.n_layers; ++li) {
         const Layer& L = e->layers[li];
         // o_proj / down_proj leave split-K partial slabs, folded in by the next norm kernel.  Prompt rows always
@@ -294,27 +296,27 @@ int run_layers(t3_engine* e, int rows, const int32_t* d_pos, const int32_t* d_st
         T3_RUN(e, K_NORM, li, 4LL * rows * D, launch_slab_add_rmsnorm(e->b->slab, li > 0 ? GEMM_SLAB_SPLIT : 0, e->b->res, L.ln1,
                                                                       e->b->xn, rows, D, c.rms_eps, st));
         GemmArgs g{};
-        g.A = e->b->xn; g.lda = D; g.Wt = L.wqkv; g.C = e->b->qkv; g.ldc = 3 * D; g.M = rows; g.N = 3 * D; g.K = D;
+        g.A = e->b->xn; g.lda = D; g.Wt = L.wqkv; g.wscale = L.sqkv; g.C = e->b->qkv; g.ldc = 3 * D; g.M = rows; g.N = 3 * D; g.K = D;
         g.n_valid = 3 * D; g.rope = e->rope; g.pos = d_pos; g.row_stream = d_stream; g.kv = kv; g.layer = li;
-        T3_RUN(e, K_QKV, li, 2LL * 3 * D * D, prefill ? launch_gemm_prompt(EPI_QKV_ROPE, g, st) : launch_gemm(EPI_QKV_ROPE, g, st));
+        T3_RUN(e, K_QKV, li, WB * 3 * D * D, prefill ? launch_gemm_prompt(EPI_QKV_ROPE, g, st) : launch_gemm(EPI_QKV_ROPE, g, st));
         if (prefill) {
             T3_RUN(e, K_ATTN_PREFILL, li, 2LL * rows * 4 * D, launch_attn_prefill(e->b->qkv, 3 * D, e->b->att, d_seq_start, d_tiles, ntiles, H, hd, st));
         } else {
             T3_RUN(e, K_ATTN_DECODE, li, e->cur_ctx_tokens * 4LL * D, launch_attn_decode(e->b->qkv, 3 * D, e->b->att, rows, d_stream, d_ctx, kv, li, st));
         }
         GemmArgs o{};
-        o.A = e->b->att; o.lda = D; o.Wt = L.wo; o.C = e->b->res; o.ldc = D; o.M = rows; o.N = D; o.K = D; o.n_valid = D;
+        o.A = e->b->att; o.lda = D; o.Wt = L.wo; o.wscale = L.so; o.C = e->b->res; o.ldc = D; o.M = rows; o.N = D; o.K = D; o.n_valid = D;
         o.slab = e->b->slab;
-        T3_RUN(e, K_OPROJ, li, 2LL * D * D, prefill ? launch_gemm_prompt(EPI_SLAB, o, st) : launch_gemm_slab(o, st));
+        T3_RUN(e, K_OPROJ, li, WB * D * D, prefill ? launch_gemm_prompt(EPI_SLAB, o, st) : launch_gemm_slab(o, st));
         T3_RUN(e, K_NORM, li, 4LL * rows * D, launch_slab_add_rmsnorm(e->b->slab, GEMM_SLAB_SPLIT, e->b->res, L.ln2, e->b->xn, rows, D,
                                                                       c.rms_eps, st));
         GemmArgs u{};
-        u.A = e->b->xn; u.lda = D; u.Wt = L.wgu; u.C = e->b->hbuf; u.ldc = F; u.M = rows; u.N = 2 * F; u.K = D; u.n_valid = 2 * F;
-        T3_RUN(e, K_GATEUP, li, 2LL * 2 * F * D, prefill ? launch_gemm_prompt(EPI_SILU, u, st) : launch_gemm(EPI_SILU, u, st));
+        u.A = e->b->xn; u.lda = D; u.Wt = L.wgu; u.wscale = L.sgu; u.C = e->b->hbuf; u.ldc = F; u.M = rows; u.N = 2 * F; u.K = D; u.n_valid = 2 * F;
+        T3_RUN(e, K_GATEUP, li, WB * 2 * F * D, prefill ? launch_gemm_prompt(EPI_SILU, u, st) : launch_gemm(EPI_SILU, u, st));
         GemmArgs dn{};
-        dn.A = e->b->hbuf; dn.lda = F; dn.Wt = L.wd; dn.C = e->b->res; dn.ldc = D; dn.M = rows; dn.N = D; dn.K = F; dn.n_valid = D;
+        dn.A = e->b->hbuf; dn.lda = F; dn.Wt = L.wd; dn.wscale = L.sd; dn.C = e->b->res; dn.ldc = D; dn.M = rows; dn.N = D; dn.K = F; dn.n_valid = D;
         dn.slab = e->b->slab;
-        T3_RUN(e, K_DOWN, li, 2LL * F * D, prefill ? launch_gemm_prompt(EPI_SLAB, dn, st) : launch_gemm_slab(dn, st));
+        T3_RUN(e, K_DOWN, li, WB * F * D, prefill ? launch_gemm_prompt(EPI_SLAB, dn, st) : launch_gemm_slab(dn, st));
     }
     T3_RUN(e, K_NORM, -1, 4LL * rows * D, launch_slab_add_rmsnorm(e->b->slab, GEMM_SLAB_SPLIT, e->b->res, e->norm_w, e->b->xn, rows, D,
                                                                   c.rms_eps, st));
@@ -664,18 +666,27 @@ extern "C" int t3_engine_finalize(t3_engine* e) {
             find_tensor(e, p + "self_attn.v_proj.weight", D, D, &v) || find_tensor(e, p + "self_attn.o_proj.weight", D, D, &o) ||
             find_tensor(e, p + "mlp.gate_proj.weight", F, D, &g) || find_tensor(e, p + "mlp.up_proj.weight", F, D, &u) ||
             find_tensor(e, p + "mlp.down_proj.weight", D, F, &d)) return 1;
-        if (dmalloc(&L.wqkv, (size_t)3 * D * D) || dmalloc(&L.wo, (size_t)D * D) || dmalloc(&L.wgu, (size_t)2 * F * D) ||
-            dmalloc(&L.wd, (size_t)D * F)) return 1;
+        // a matrix in its streaming order: bf16 tiles, or (weight_int8) int8 pair tiles + one scale per output column
+        const bool w8 = c.weight_int8 != 0;
+        auto place = [&](const bf16_t* src, bf16_t** wt, float** sc, int N, int K) -> int {
+            if (!w8) {
+                if (dmalloc(wt, (size_t)N * K)) return 1;
+                return launch_repack(src, *wt, N, K, st);
+            }
+            T3_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(wt), (size_t)N * K));
+            T3_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(sc), sizeof(float) * N));
+            return launch_quantize(src, reinterpret_cast<uint8_t*>(*wt), *sc, N, K, st);
+        };
         const size_t dd = (size_t)D * D * sizeof(bf16_t), fd = (size_t)F * D * sizeof(bf16_t);
         T3_HIP_CHECK(hipMemcpyAsync(cat, q, dd, hipMemcpyDeviceToDevice, st));
         T3_HIP_CHECK(hipMemcpyAsync(cat + (size_t)D * D, k, dd, hipMemcpyDeviceToDevice, st));
         T3_HIP_CHECK(hipMemcpyAsync(cat + (size_t)2 * D * D, v, dd, hipMemcpyDeviceToDevice, st));
-        if (launch_repack(cat, L.wqkv, 3 * D, D, st)) return 1;
-        if (launch_repack(o, L.wo, D, D, st)) return 1;
+        if (place(cat, &L.wqkv, &L.sqkv, 3 * D, D)) return 1;
+        if (place(o, &L.wo, &L.so, D, D)) return 1;
         T3_HIP_CHECK(hipMemcpyAsync(cat, g, fd, hipMemcpyDeviceToDevice, st));
         T3_HIP_CHECK(hipMemcpyAsync(cat + (size_t)F * D, u, fd, hipMemcpyDeviceToDevice, st));
-        if (launch_repack(cat, L.wgu, 2 * F, D, st)) return 1;
-        if (launch_repack(d, L.wd, D, F, st)) return 1;
+        if (place(cat, &L.wgu, &L.sgu, 2 * F, D)) return 1;
+        if (place(d, &L.wd, &L.sd, D, F)) return 1;
         for (const char* s : {"self_attn.q_proj.weight", "self_attn.k_proj.weight", "self_attn.v_proj.weight",
                               "self_attn.o_proj.weight", "mlp.gate_proj.weight", "mlp.up_proj.weight", "mlp.down_proj.weight"})
             consumed.push_back(p + s);
@@ -696,7 +707,10 @@ extern "C" int t3_engine_destroy(t3_engine* e) {
     (void)hipStreamSynchronize(e->stream);
     for (auto& kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
     for (auto& kv : e->raw) (void)hipFree(kv.second.p);
-    for (auto& L : e->layers) { (void)hipFree(L.wqkv); (void)hipFree(L.wo); (void)hipFree(L.wgu); (void)hipFree(L.wd); }
+    for (auto& L : e->layers) {
+        (void)hipFree(L.wqkv); (void)hipFree(L.wo); (void)hipFree(L.wgu); (void)hipFree(L.wd);
+        (void)hipFree(L.sqkv); (void)hipFree(L.so); (void)hipFree(L.sgu); (void)hipFree(L.sd);
+    }
     (void)hipFree(e->head); (void)hipFree(e->kv_pool);
     {
         auto& b = e->bufs;

@@ -23,9 +23,26 @@
 //   EPI_SILU      h = bf16(bf16(silu(g)) * u), g/u = n-blocks b and b + F/16   (gate_up_proj)
 //   EPI_QKV_ROPE  half-split RoPE on q,k (n-blocks j and j+32 columns of one head), store the
 //                 rotated q|k|v row and scatter k, v into the paged KV cache.
+//
+// int8 weights (W8 = true, GemmArgs::wscale != nullptr): W8A16 with one fp32 scale per output
+// column, W[n][k] = wscale[n] * (u8[n][k] - 128).  Two k-tiles share a 1 KiB tile (tile (nb, kp):
+// byte lane*16 + t*8 + j = u8[nb*16 + (lane&15)][kp*64 + t*32 + 8*(lane>>4) + j]), so a lane's
+// 16-byte load still is 1 KiB of contiguous memory per wave; the bytes become exact bf16 integers
+// in registers, the MFMA runs as before and the scale multiplies the fp32 sum before the one rounding.
 #include "t3_common.h"
 
-template <int NB, int MT, int KW, int KT, int EPI>
+// 8 offset-binary bytes (two dwords) -> 8 bf16 values u - 128 (exact: |u - 128| <= 128)
+__device__ __forceinline__ bf16x8 dequant8(unsigned lo, unsigned hi) {
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        r[j] = (__bf16)((float)((lo >> (8 * j)) & 0xffu) - 128.0f);
+        r[4 + j] = (__bf16)((float)((hi >> (8 * j)) & 0xffu) - 128.0f);
+    }
+    return r;
+}
+
+template <int NB, int MT, int KW, int KT, int EPI, bool W8>
 __global__ __launch_bounds__(KW * 64) void gemm_stream_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) float red_raw[];
     f32x4* red = reinterpret_cast<f32x4*>(red_raw);
@@ -87,12 +104,24 @@ __global__ __launch_bounds__(KW * 64) void gemm_stream_kernel(GemmArgs a) {
         }
     }
     // weight fragments: the HBM stream
-    bf16x8 wf[NB][KT];
+    constexpr int NWF = W8 ? 1 : KT, NWQ = W8 ? KT / 2 : 1;
+    bf16x8 wf[NB][NWF];
+    u32x4 wq[NB][NWQ];
+    if constexpr (W8) {
+        static_assert(!W8 || KT % 2 == 0, "int8 tiles hold two k-tiles");
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        const bf16x8* wp = reinterpret_cast<const bf16x8*>(a.Wt) + ((size_t)nbi[nb] * ktiles + kt0) * 64 + lane;
+        for (int nb = 0; nb < NB; ++nb) {
+            const u32x4* wp = reinterpret_cast<const u32x4*>(a.Wt) + ((size_t)nbi[nb] * (ktiles >> 1) + (kt0 >> 1)) * 64 + lane;
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt) wf[nb][kt] = __builtin_nontemporal_load(wp + kt * 64);
+            for (int kp = 0; kp < NWQ; ++kp) wq[nb][kp] = __builtin_nontemporal_load(wp + kp * 64);
+        }
+    } else {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const bf16x8* wp = reinterpret_cast<const bf16x8*>(a.Wt) + ((size_t)nbi[nb] * ktiles + kt0) * 64 + lane;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) wf[nb][kt] = __builtin_nontemporal_load(wp + kt * 64);
+        }
     }
     u32x2 pre_cs = {0u, 0u}, pre_sn = {0u, 0u};
     int pre_page = 0;
@@ -113,10 +142,20 @@ __global__ __launch_bounds__(KW * 64) void gemm_stream_kernel(GemmArgs a) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const bf16x8*>(arow[mt] + kt * 32);
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
+        for (int nb = 0; nb < NB; ++nb) {
+            bf16x8 wv;
+            if constexpr (W8) wv = dequant8(wq[nb][kt >> 1][2 * (kt & 1)], wq[nb][kt >> 1][2 * (kt & 1) + 1]);
+            else wv = wf[nb][kt];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
-                acc[nb][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb][kt], af[mt], acc[nb][mt], 0, 0, 0);
+                acc[nb][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, af[mt], acc[nb][mt], 0, 0, 0);
+        }
+    }
+    f32x4 wsc[NB];
+    if constexpr (W8) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+            wsc[nb] = *reinterpret_cast<const f32x4*>(a.wscale + nbi[nb] * 16 + 4 * (lane >> 4));
     }
 
     T3_STAMP(1);
@@ -139,6 +178,7 @@ __global__ __launch_bounds__(KW * 64) void gemm_stream_kernel(GemmArgs a) {
             s[nb] = red[(nb * MT + mt) * 64 + lane];
 #pragma unroll
             for (int w2 = 1; w2 < KW; ++w2) s[nb] += red[(w2 * NT + nb * MT + mt) * 64 + lane];
+            if constexpr (W8) s[nb] *= wsc[nb];
         }
         const int r = m0 + mt * 16 + (lane & 15);
         if (r >= a.M) continue;
@@ -243,19 +283,74 @@ int launch_repack(const bf16_t* w, bf16_t* wt, int N, int K, hipStream_t st) {
     return 0;
 }
 
-template <int NB, int MT, int KW, int KT, int EPI>
-static int launch_one(const GemmArgs& a, int nblocks, hipStream_t st, int ksplit = 1) {
+// int8 quantisation of one weight row per workgroup: scale = absmax / 127, q = rint(w / scale) (ties to
+// even, as torch.round), stored offset-binary in the pair-tile order the W8 kernels read.
+__global__ __launch_bounds__(256) void quantize_kernel(const bf16_t* __restrict__ w, uint8_t* __restrict__ wq,
+                                                       float* __restrict__ scale, int K) {
+    __shared__ float part[4];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const bf16_t* row = w + (size_t)n * K;
+    float amax = 0.f;
+    for (int k = tid * 8; k < K; k += 256 * 8) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(row + k);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) amax = fmaxf(amax, fmaxf(fabsf(bf_lo(v[i])), fabsf(bf_hi(v[i]))));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+    if ((tid & 63) == 0) part[tid >> 6] = amax;
+    __syncthreads();
+    amax = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+    const float sc = amax > 0.f ? amax / 127.0f : 1.0f;
+    if (tid == 0) scale[n] = sc;
+    const int nb = n >> 4, nr = n & 15, kpairs = K >> 6;
+    for (int k8 = tid; k8 < (K >> 3); k8 += 256) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(row + k8 * 8);
+        unsigned b[2] = {0u, 0u};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float x = (j & 1) ? bf_hi(v[j >> 1]) : bf_lo(v[j >> 1]);
+            float q = rintf(x / sc);
+            q = fminf(fmaxf(q, -127.0f), 127.0f);
+            b[j >> 2] |= (unsigned)((int)q + 128) << (8 * (j & 3));
+        }
+        const int kp = k8 >> 3, t = (k8 >> 2) & 1, lane = (k8 & 3) * 16 + nr;
+        const u32x2 o = {b[0], b[1]};
+        *reinterpret_cast<u32x2*>(wq + (((size_t)nb * kpairs + kp) * 64 + lane) * 16 + t * 8) = o;
+    }
+}
+
+int launch_quantize(const bf16_t* w, uint8_t* wq, float* scale, int N, int K, hipStream_t st) {
+    T3_REQUIRE(N % 16 == 0 && K % 64 == 0, "quantize: N must be a multiple of 16 and K of 64");
+    T3_LAUNCH(quantize_kernel, dim3(N), dim3(256), 0, st, w, wq, scale, K);
+    T3_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+template <int NB, int MT, int KW, int KT, int EPI, bool W8>
+static int launch_w(const GemmArgs& a, int nblocks, hipStream_t st, int ksplit) {
     constexpr size_t lds = (size_t)KW * NB * MT * 64 * sizeof(f32x4);
     static bool attr_set = false;
     if (!attr_set) {
-        T3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_stream_kernel<NB, MT, KW, KT, EPI>),
+        T3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_stream_kernel<NB, MT, KW, KT, EPI, W8>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     const int groups = (a.M + MT * 16 - 1) / (MT * 16);
-    T3_LAUNCH((gemm_stream_kernel<NB, MT, KW, KT, EPI>), dim3(nblocks, groups, ksplit), dim3(KW * 64), lds, st, a);
+    T3_LAUNCH((gemm_stream_kernel<NB, MT, KW, KT, EPI, W8>), dim3(nblocks, groups, ksplit), dim3(KW * 64), lds, st, a);
     T3_HIP_CHECK(hipGetLastError());
     return 0;
+}
+
+// bf16 or int8 weights by GemmArgs::wscale; KT odd has no int8 form (its callers never pass a scale)
+template <int NB, int MT, int KW, int KT, int EPI>
+static int launch_one(const GemmArgs& a, int nblocks, hipStream_t st, int ksplit = 1) {
+    if constexpr (KT % 2 == 0) {
+        if (a.wscale) return launch_w<NB, MT, KW, KT, EPI, true>(a, nblocks, st, ksplit);
+    } else {
+        T3_REQUIRE(a.wscale == nullptr, "gemm: this shape has no int8 form");
+    }
+    return launch_w<NB, MT, KW, KT, EPI, false>(a, nblocks, st, ksplit);
 }
 
 template <int NB, int KW, int KT, int EPI>
@@ -303,6 +398,7 @@ int launch_gemm(int epi, const GemmArgs& a, hipStream_t st) {
 // are summed in split order by the residual-add + RMSNorm kernel that follows.
 int launch_gemm_slab(const GemmArgs& a, hipStream_t st) {
     T3_REQUIRE(a.slab != nullptr && a.M >= 1 && a.N % 32 == 0 && a.lda % 8 == 0, "gemm_slab: bad arguments");
+    if (a.K == 1024 && a.wscale) return launch_mt<2, 2, 2, EPI_SLAB>(a, a.N / 32, st, GEMM_SLAB_SPLIT);   // int8: 2 waves x 1 tile pair
     if (a.K == 1024) return launch_mt<2, 4, 1, EPI_SLAB>(a, a.N / 32, st, GEMM_SLAB_SPLIT);   // 4 waves x 1 k-tile
     if (a.K == 4096) return launch_mt<2, 8, 2, EPI_SLAB>(a, a.N / 32, st, GEMM_SLAB_SPLIT);   // 8 waves x 2 k-tiles
     t3_set_error("gemm_slab: K must be 1024 or 4096");

@@ -18,6 +18,10 @@
 // not depend on the other rows of the launch.  It does differ in rounding from gemm.hip's 8-wave
 // K split, which is why the engine sends prompt rows here and decode rows there, always.
 //
+// int8 weights (GemmArgs::wscale set): the W block of a k-step is 8 pair tiles of 1 KiB (gemm.hip), staged as
+// bytes; a lane reads its 16 bytes once per k-step and turns them into the two bf16 fragments in registers; the
+// per-column scale multiplies the fp32 sums in the epilogue.
+//
 // Epilogues: EPI_QKV_ROPE (a wave's 64 columns are one head: RoPE pairs (c, c+32) sit in one lane;
 // q|k|v row store + KV-cache scatter), EPI_SILU (a workgroup takes 64 gate and the matching 64 up
 // columns), EPI_SLAB (split-K 8 fp32 partials for o_proj / down_proj, summed by the norm kernel).
@@ -31,9 +35,19 @@ constexpr int PA_ELEMS = PBM * PA_STRIDE;            // 9216
 constexpr int PW_ELEMS = 8 * 2 * 512;                // 8 n-blocks x 2 k-tiles x 512 elements
 constexpr int PSTAGE = PA_ELEMS + PW_ELEMS;          // 17408 elements = 34816 bytes
 
+__device__ __forceinline__ bf16x8 prompt_dequant8(unsigned lo, unsigned hi) {
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        r[j] = (__bf16)((float)((lo >> (8 * j)) & 0xffu) - 128.0f);
+        r[4 + j] = (__bf16)((float)((hi >> (8 * j)) & 0xffu) - 128.0f);
+    }
+    return r;
+}
+
 }  // namespace
 
-template <int EPI>
+template <int EPI, bool W8>
 __global__ __launch_bounds__(256) void gemm_prompt_kernel(GemmArgs a, int m_tiles, int n_tiles, int ksplit, int per_xcd) {
     extern __shared__ __attribute__((aligned(16))) bf16_t plds[];
     const int tid = threadIdx.x;
@@ -82,15 +96,22 @@ __global__ __launch_bounds__(256) void gemm_prompt_kernel(GemmArgs a, int m_tile
         ag[i] = a.A + (size_t)r * a.lda + k0 + chunk * 8;
         a_lds[i] = row * PA_STRIDE + chunk * 8;
     }
-    const bf16_t* wg[4];
-    int w_lds[4];
+    constexpr int NWU = W8 ? 2 : 4;                   // 16-byte units of W per thread and k-step
+    const bf16_t* wg[NWU];
+    int w_lds[NWU];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int idx = i * 256 + tid;                // 16-byte unit 0..1023 of the stage's W block
-        const int slot = idx >> 7, within = idx & 127;
-        wg[i] = a.Wt + ((size_t)nb_of(slot) * ktiles + (k0 >> 5)) * 512 + within * 8;
+    for (int i = 0; i < NWU; ++i) {
+        const int idx = i * 256 + tid;                // 16-byte unit of the stage's W block (1024 bf16 / 512 int8 units)
+        if constexpr (W8) {
+            const int slot = idx >> 6, within = idx & 63;       // one 1 KiB pair tile per n-block
+            wg[i] = a.Wt + (((size_t)nb_of(slot) * (ktiles >> 1) + (k0 >> 6)) * 64 + within) * 8;
+        } else {
+            const int slot = idx >> 7, within = idx & 127;
+            wg[i] = a.Wt + ((size_t)nb_of(slot) * ktiles + (k0 >> 5)) * 512 + within * 8;
+        }
         w_lds[i] = PA_ELEMS + idx * 8;
     }
+    constexpr int W_STEP = W8 ? 512 : 1024;           // bf16_t units the W pointer advances per k-step
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -98,19 +119,19 @@ __global__ __launch_bounds__(256) void gemm_prompt_kernel(GemmArgs a, int m_tile
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    u32x4 ra[4], rw[4];
+    u32x4 ra[4], rw[NWU];
 #pragma unroll
     for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const u32x4*>(ag[i]);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) rw[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wg[i]));
+    for (int i = 0; i < NWU; ++i) rw[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wg[i]));
 #pragma unroll
     for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(plds + a_lds[i]) = ra[i];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(plds + w_lds[i]) = rw[i];
+    for (int i = 0; i < NWU; ++i) *reinterpret_cast<u32x4*>(plds + w_lds[i]) = rw[i];
     __syncthreads();
 
     const int a_frag = (wm * 64 + (lane & 15)) * PA_STRIDE + 8 * (lane >> 4);
-    const int w_frag = PA_ELEMS + wn * 4 * 1024 + lane * 8;
+    const int w_frag = W8 ? PA_ELEMS + wn * 4 * 512 + lane * 8 : PA_ELEMS + wn * 4 * 1024 + lane * 8;
     for (int ks = 0; ks < nks; ++ks) {
         const bf16_t* cur = plds + (ks & 1) * PSTAGE;
         const bool more = ks + 1 < nks;
@@ -118,8 +139,13 @@ __global__ __launch_bounds__(256) void gemm_prompt_kernel(GemmArgs a, int m_tile
 #pragma unroll
             for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const u32x4*>(ag[i] + (ks + 1) * PBK);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                rw[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wg[i] + (size_t)(ks + 1) * 1024));
+            for (int i = 0; i < NWU; ++i)
+                rw[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wg[i] + (size_t)(ks + 1) * W_STEP));
+        }
+        u32x4 wq[4];
+        if constexpr (W8) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) wq[ni] = *reinterpret_cast<const u32x4*>(cur + w_frag + ni * 512);
         }
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
@@ -128,8 +154,10 @@ __global__ __launch_bounds__(256) void gemm_prompt_kernel(GemmArgs a, int m_tile
             for (int mi = 0; mi < 4; ++mi)
                 af[mi] = *reinterpret_cast<const bf16x8*>(cur + a_frag + mi * 16 * PA_STRIDE + kt * 32);
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
-                wf[ni] = *reinterpret_cast<const bf16x8*>(cur + w_frag + ni * 1024 + kt * 512);
+            for (int ni = 0; ni < 4; ++ni) {
+                if constexpr (W8) wf[ni] = prompt_dequant8(wq[ni][2 * kt], wq[ni][2 * kt + 1]);
+                else wf[ni] = *reinterpret_cast<const bf16x8*>(cur + w_frag + ni * 1024 + kt * 512);
+            }
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -141,9 +169,17 @@ __global__ __launch_bounds__(256) void gemm_prompt_kernel(GemmArgs a, int m_tile
 #pragma unroll
             for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(nxt + a_lds[i]) = ra[i];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(nxt + w_lds[i]) = rw[i];
+            for (int i = 0; i < NWU; ++i) *reinterpret_cast<u32x4*>(nxt + w_lds[i]) = rw[i];
         }
         __syncthreads();
+    }
+    if constexpr (W8) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(a.wscale + nb_of(wn * 4 + ni) * 16 + 4 * (lane >> 4));
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) acc[mi][ni] *= sc;
+        }
     }
 
     // ---- epilogue: lane holds columns 4*(lane>>4)..+3 of n-block `ni`, row (lane & 15) of row tile `mi`
@@ -217,21 +253,25 @@ __global__ __launch_bounds__(256) void gemm_prompt_kernel(GemmArgs a, int m_tile
     }
 }
 
-template <int EPI>
-static int launch_prompt(const GemmArgs& a, int n_tiles, int ksplit, hipStream_t st) {
+template <int EPI, bool W8>
+static int launch_prompt_w(const GemmArgs& a, int n_tiles, int ksplit, hipStream_t st) {
     constexpr size_t lds = 2 * (size_t)PSTAGE * sizeof(bf16_t);
     static bool attr_set = false;
     if (!attr_set) {
-        T3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_prompt_kernel<EPI>),
+        T3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_prompt_kernel<EPI, W8>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     const int m_tiles = (a.M + PBM - 1) / PBM;
     const int total = m_tiles * n_tiles * ksplit;
     const int per_xcd = (total + 7) / 8;
-    T3_LAUNCH((gemm_prompt_kernel<EPI>), dim3(per_xcd * 8), dim3(256), lds, st, a, m_tiles, n_tiles, ksplit, per_xcd);
+    T3_LAUNCH((gemm_prompt_kernel<EPI, W8>), dim3(per_xcd * 8), dim3(256), lds, st, a, m_tiles, n_tiles, ksplit, per_xcd);
     T3_HIP_CHECK(hipGetLastError());
     return 0;
+}
+template <int EPI>
+static int launch_prompt(const GemmArgs& a, int n_tiles, int ksplit, hipStream_t st) {
+    return a.wscale ? launch_prompt_w<EPI, true>(a, n_tiles, ksplit, st) : launch_prompt_w<EPI, false>(a, n_tiles, ksplit, st);
 }
 
 int launch_gemm_prompt(int epi, const GemmArgs& a, hipStream_t st) {

@@ -76,7 +76,8 @@ enum GemmEpilogue { EPI_STORE = 0, EPI_RESID = 1, EPI_SILU = 2, EPI_QKV_ROPE = 3
 struct GemmArgs {
     const bf16_t* A; int lda;          // activations [M, K]
     const int32_t* a_rows;             // optional gather of A rows (nullptr = identity)
-    const bf16_t* Wt;                  // weights in tile order
+    const bf16_t* Wt;                  // weights in tile order (bf16 tiles, or int8 pair tiles when wscale is set)
+    const float* wscale;               // int8 weights: one scale per output column, nullptr = bf16 weights
     bf16_t* C; int ldc;                // output
     int M, N, K;
     int n_valid;                       // columns >= n_valid are not stored (EPI_STORE)
@@ -109,6 +110,8 @@ int launch_gemm_prompt(int epi, const GemmArgs& a, hipStream_t st);
 int launch_slab_add_rmsnorm(const float* slab, int nsplit, bf16_t* res, const bf16_t* w, bf16_t* xn, int rows, int d,
                             float eps, hipStream_t st);
 int launch_repack(const bf16_t* w, bf16_t* wt, int N, int K, hipStream_t st);
+// W[N,K] bf16 -> int8 pair tiles (offset binary) + scale[N] = absmax(row) / 127 (1 for an all-zero row)
+int launch_quantize(const bf16_t* w, uint8_t* wq, float* scale, int N, int K, hipStream_t st);
 int launch_add_rmsnorm(const bf16_t* x, bf16_t* res, const bf16_t* w, bf16_t* xn, int rows, int d,
                        float eps, hipStream_t st);
 int launch_attn_decode(const bf16_t* qkv, int ldq, bf16_t* out, int rows, const int32_t* row_stream,

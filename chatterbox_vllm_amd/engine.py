@@ -77,7 +77,8 @@ class T3Engine:
                  tokenizer: Optional[Callable[..., List[int]]] = None, *,
                  max_model_len: int = 1000, max_num_seqs: int = 32, cfg_scale: Optional[float] = None,
                  cfg_paired: Optional[bool] = None, device: int = 0, enforce_eager: bool = False,
-                 kv_pages: int = 0, max_prefill_rows: int = 2048, **_ignored_vllm_kwargs):
+                 kv_pages: int = 0, max_prefill_rows: int = 2048, quantization: Optional[str] = None,
+                 **_ignored_vllm_kwargs):
         if cfg_scale is None:                      # models/t3/t3.py:343
             cfg_scale = float(os.environ.get("CHATTERBOX_CFG_SCALE", "0.5"))
         if cfg_paired is None:
@@ -89,6 +90,9 @@ class T3Engine:
         self.cfg_scale = float(cfg_scale)
         self.cfg_paired = bool(cfg_paired)
         self.device = int(device)
+        if quantization not in (None, "int8"):
+            raise ValueError(f"unsupported quantization {quantization!r}: None or 'int8' (W8A16, per output channel)")
+        self.quantization = quantization
         self._lib = _capi.load()
         m = model_config
         cfg = _capi.T3Config(
@@ -96,7 +100,7 @@ class T3Engine:
             text_vocab=m.text_vocab, speech_vocab=m.speech_vocab, text_pos_rows=m.text_pos_rows,
             speech_pos_rows=m.speech_pos_rows, max_model_len=self.max_model_len, max_num_seqs=self.max_num_seqs,
             cfg_paired=int(self.cfg_paired), max_prefill_rows=int(max_prefill_rows), device=self.device,
-            use_graphs=int(not enforce_eager), reserved0=0, cfg_scale=self.cfg_scale, rms_eps=m.rms_eps,
+            use_graphs=int(not enforce_eager), weight_int8=int(quantization == "int8"), cfg_scale=self.cfg_scale, rms_eps=m.rms_eps,
             kv_pages=int(kv_pages))
         self._h = C.c_void_p()
         _capi.check(self._lib, self._lib.t3_engine_create(C.byref(cfg), C.byref(self._h)))

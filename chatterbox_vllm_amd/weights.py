@@ -111,3 +111,30 @@ def route_checkpoint(items: Iterable[Tuple[str, torch.Tensor]], cfg: T3ModelConf
     if missing:
         raise KeyError(f"checkpoint is missing {len(missing)} tensors, first: {missing[:3]}")
     return keep, skipped
+
+
+PROJECTION_SUFFIXES = ("self_attn.q_proj.weight", "self_attn.k_proj.weight", "self_attn.v_proj.weight",
+                       "self_attn.o_proj.weight", "mlp.gate_proj.weight", "mlp.up_proj.weight", "mlp.down_proj.weight")
+
+
+def quantize_int8(w: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """The engine's W8A16 rule for one projection matrix [N, K] (``quantization="int8"``): per output row,
+    scale = absmax / 127 in fp32 (1 for an all-zero row), q = round-half-even(w / scale) clamped to +-127.
+    Returns (q int8 [N, K], scale fp32 [N]).  The engine quantises on the device with the same arithmetic."""
+    wf = w.detach().to(torch.float32)
+    amax = wf.abs().amax(dim=1)
+    scale = torch.where(amax > 0, amax / 127.0, torch.ones_like(amax))
+    q = torch.round(wf / scale[:, None]).clamp_(-127, 127).to(torch.int8)
+    return q, scale
+
+
+def int8_dequantized_state_dict(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """``sd`` with every backbone projection replaced by scale * q (fp32): the weights an int8 engine
+    computes with, for checkers that want to follow it exactly.  Embeddings, norms and the speech head
+    stay as they are (the engine keeps them bf16)."""
+    out = dict(sd)
+    for name, t in sd.items():
+        if name.startswith("tfmr.layers.") and name.endswith(PROJECTION_SUFFIXES):
+            q, scale = quantize_int8(t)
+            out[name] = q.to(torch.float32) * scale[:, None]
+    return out

@@ -39,7 +39,8 @@ typedef struct t3_config {
     int32_t max_prefill_rows;  /* prompt rows (per stream) admitted in one step       */
     int32_t device;            /* HIP device ordinal                                  */
     int32_t use_graphs;        /* 1: replay decode steps from captured HIP graphs     */
-    int32_t reserved0;
+    int32_t weight_int8;       /* 1: backbone projections held as int8 + one fp32 scale per output
+                                  column (W8A16, quantised at t3_engine_finalize); head stays bf16 */
     float cfg_scale;           /* CHATTERBOX_CFG_SCALE, models/t3/t3.py:343           */
     float rms_eps;
     int64_t kv_pages;          /* KV pool size in 64-token pages; 0 = no oversubscription */
@@ -169,6 +170,25 @@ int t3_op_gemm_prompt_qkv_rope(const void* a_dev, const void* wt_dev, void* qkv_
                                int32_t K, const void* rope_dev, const int32_t* pos_dev, const int32_t* stream_dev,
                                void* kv_pool_dev, int64_t layer_stride_elems, int32_t layer,
                                const int32_t* block_table_dev, int32_t max_pages, void* stream);
+/* int8 weights (the engine's weight_int8 mode): W[N,K] bf16 -> wq_dev (N*K bytes, offset-binary int8 in the
+ * pair-tile order the kernels stream) and scale_dev[N] = absmax(row)/127; q = rint(w/scale), ties to even.
+ * N % 16 == 0, K % 64 == 0.  The reference has no quantised path (weights are bf16 under vLLM, t3.py:305-379). */
+int t3_op_quantize_weight(const void* w_dev, void* wq_dev, float* scale_dev, int32_t N, int32_t K, void* stream);
+/* Every projection form behind one descriptor: what the entry points above do, plus int8 weights. */
+typedef struct t3_gemm_desc {
+    const void* a_dev;            /* activations [M, K] bf16, row-major                               */
+    const void* w_dev;            /* bf16 tile order, or int8 pair tiles when w_scale_dev != NULL     */
+    const float* w_scale_dev;     /* [N] or NULL                                                      */
+    void* out_dev;                /* epilogue 0/1: [M, ldc]; 2: h [M, N/2]; 3: qkv [M, N]; 4: unused  */
+    float* slab_dev;              /* epilogue 4: [t3_op_slab_split()][M][N] fp32                      */
+    int32_t M, N, K, ldc;
+    int32_t epilogue;             /* 0 store, 1 residual add, 2 SiLU-mul, 3 q|k|v + RoPE + cache write, 4 split-K slabs */
+    int32_t prompt_form;          /* 0: weight-streaming kernel; 1: LDS-tiled prompt kernel (epilogues 2, 3, 4) */
+    int32_t H, hd, layer, max_pages;                           /* epilogue 3, as t3_op_gemm_qkv_rope   */
+    const void* rope_dev; const int32_t* pos_dev; const int32_t* stream_dev; void* kv_pool_dev;
+    int64_t layer_stride_elems; const int32_t* block_table_dev;
+} t3_gemm_desc;
+int t3_op_gemm_ex(const t3_gemm_desc* desc, void* stream);
 /* Single-query attention over the paged KV cache: row r attends to positions
  * [0, ctx_dev[r]) of KV stream stream_dev[r]; q is read from qkv_dev[r, 0:H*hd]. */
 int t3_op_attn_decode(const void* qkv_dev, void* out_dev, int32_t rows, int32_t H, int32_t hd,

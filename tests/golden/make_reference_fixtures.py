@@ -232,6 +232,42 @@ def main():
         lens.append(len(en_tok.encode(s.replace(" ", "[SPACE]")).ids))
         chars.append(sum(1 for ch in re.sub(r"\[[^\]]+\]", "", s) if not ch.isspace()))
     tj["benchmark_text_1"] = {"n_chunks": len(chunks), "text_id_counts": lens, "nonspace_chars": chars}
+
+    # benchmark-multilingual-fr.py / -zh.py: same chunker (400 characters at ". " / 50 characters at the
+    # ideographic full stop), ids from the multilingual vocabulary as mtl_tokenizer.py:358-390 forms them
+    # (lower-case + NFKD, language tag first).  zh: the Cangjie table (mtl_tokenizer.py:139-143) is a download
+    # and absent here, so the Han characters go through the vocabulary as they are; the count is recorded as such.
+    def split_generic(text, max_chunk, sep):
+        sentences = text.split(sep)
+        n_chunks = len(text) // max_chunk + 1
+        approx = len(text) // n_chunks
+        chunks, cur, cur_len = [], [], 0
+        for s in sentences:
+            s = " ".join(s.split()).strip()
+            if cur_len + len(s) > approx:
+                chunks.append(sep.join(cur))
+                cur, cur_len = [s], len(s)
+            else:
+                cur.append(s)
+                cur_len += len(s)
+        if cur:
+            chunks.append(sep.join(cur))
+        return [c + sep if re.match(r"[a-zA-Z0-9]", c[-1]) else c for c in chunks if len(c) > 0]
+
+    for tag, fname, size, sep in (("fr", "docs/benchmark-text-fr-1.txt", 400, ". "), ("zh", "docs/benchmark-text-zh-1.txt", 50, "\u3002")):
+        with open(os.path.join(REF, fname)) as f:
+            text = f.read()
+        lines = [l.strip() for l in text.split("\n") if not l.startswith("#") and l.strip()]
+        chunks = [c for l in lines for c in split_generic(l, size, sep)]
+        lens, chars = [], []
+        for c in chunks:
+            s_ = "[START]" + text_utils.punc_norm(c) + "[STOP]"
+            pre = normalize("NFKD", s_.lower()).replace("[start]", "[START]").replace("[stop]", "[STOP]")
+            lens.append(len(mtl_tok.encode(("[%s]" % tag + pre).replace(" ", "[SPACE]")).ids))
+            chars.append(sum(1 for ch in c if not ch.isspace()))
+        tj["benchmark_text_%s_1" % tag] = {"n_chunks": len(chunks), "text_id_counts": lens, "nonspace_chars": chars,
+                                            "cangjie": False}
+        print("benchmark", tag, "chunks", len(chunks), "ids", min(lens), "-", max(lens))
     with open(os.path.join(HERE, "ref_text_fixture.json"), "w") as f:
         json.dump(tj, f, ensure_ascii=False, indent=0)
     print("wrote ref_text_fixture.json: chunks", len(chunks), "mean ids", sum(lens) / len(lens), "max", max(lens))

@@ -338,3 +338,108 @@ def test_split_k_slabs_then_residual_norm(capi, M, K, form):
     call(capi, "t3_op_slab_add_rmsnorm", None, 0, p(res2), p(g), p(xn), M, N, C.c_float(1e-5), None)
     torch.cuda.synchronize()
     assert torch.equal(res2, res0)
+
+
+# ---- int8 weights (W8A16, one scale per output column) ---------------------------------------------
+def _quantized(capi, w):
+    """Device quantisation of W [N,K] -> (pair-tile bytes, scales), checked against the host rule."""
+    N, K = w.shape
+    wq = torch.zeros(N * K, dtype=torch.uint8, device=DEV)
+    sc = torch.zeros(N, dtype=torch.float32, device=DEV)
+    call(capi, "t3_op_quantize_weight", p(w), p(wq), p(sc), N, K, None)
+    torch.cuda.synchronize()
+    return wq, sc
+
+
+def _untile_int8(wq, N, K):
+    """pair-tile bytes -> q [N, K] (int): byte (lane*16 + t*8 + j) of tile (nb, kp) is
+    u8[nb*16 + lane%16][kp*64 + t*32 + 8*(lane//16) + j]."""
+    t = wq.cpu().view(N // 16, K // 64, 4, 16, 2, 8).to(torch.int32) - 128      # nb, kp, lane//16, lane%16, t, j
+    return t.permute(0, 3, 1, 4, 2, 5).reshape(N, K)                            # nb, nr, kp, t, g, j
+
+
+@pytest.mark.parametrize("N,K", [(1024, 1024), (1024, 4096), (3072, 1024)])
+def test_quantize_weight_matches_host_rule(capi, N, K):
+    w = _rand((N, K), 80, 0.02)
+    w[5] = 0                                                   # an all-zero row keeps scale 1
+    w[7, 3] = 0.5                                              # an outlier sets its row's scale
+    wd = w.to(DEV)
+    wq, sc = _quantized(capi, wd)
+    q_ref, s_ref = W.quantize_int8(w)
+    assert torch.equal(sc.cpu(), s_ref)
+    assert torch.equal(_untile_int8(wq, N, K), q_ref.to(torch.int32))
+
+
+def _desc(**kw):
+    from chatterbox_vllm_amd._capi import T3GemmDesc
+    d = T3GemmDesc()
+    for k, v in kw.items():
+        setattr(d, k, v.data_ptr() if isinstance(v, torch.Tensor) else v)
+    return d
+
+
+@pytest.mark.parametrize("prompt", [0, 1])
+@pytest.mark.parametrize("M", [1, 33, 64, 200])
+def test_int8_projections_match_dequantised_weights(capi, M, prompt):
+    """Every int8 projection form against fp32 matmul with scale * q: same contract as the bf16 forms."""
+    H, hd, K, F = 16, 64, 1024, 4096
+    a = _rand((M, K), 81).to(DEV)
+    # store / residual (decode form only), SiLU, split-K slabs
+    w = _rand((2 * F, K), 82, 0.05).to(DEV)
+    wq, sc = _quantized(capi, w)
+    wdq = (W.quantize_int8(w.cpu())[0].float() * sc.cpu()[:, None]).to(DEV)
+    ref = a.float() @ wdq.T
+    if not prompt:
+        out = torch.zeros(M, 2 * F, dtype=torch.bfloat16, device=DEV)
+        d = _desc(a_dev=a, w_dev=wq, w_scale_dev=sc, out_dev=out, M=M, N=2 * F, K=K, ldc=2 * F, epilogue=0)
+        call(capi, "t3_op_gemm_ex", C.byref(d), None)
+        torch.cuda.synchronize()
+        assert_bf16_close(out, ref, what="int8 store")
+    h = torch.zeros(M, F, dtype=torch.bfloat16, device=DEV)
+    d = _desc(a_dev=a, w_dev=wq, w_scale_dev=sc, out_dev=h, M=M, N=2 * F, K=K, epilogue=2, prompt_form=prompt)
+    call(capi, "t3_op_gemm_ex", C.byref(d), None)
+    torch.cuda.synchronize()
+    gu = r16(ref)
+    g, u = gu[:, :F], gu[:, F:]
+    assert_bf16_close(h, r16(g / (1 + torch.exp(-g))) * u, ulps=3, max_frac=0.03, what="int8 silu")
+    S = capi.t3_op_slab_split()
+    for Kd in (1024, 4096):
+        ad = _rand((M, Kd), 83).to(DEV)
+        wd_ = _rand((1024, Kd), 84, 0.02).to(DEV)
+        wdq_, scd = _quantized(capi, wd_)
+        deq = (W.quantize_int8(wd_.cpu())[0].float() * scd.cpu()[:, None]).to(DEV)
+        slab = torch.full((S, M, 1024), float("nan"), device=DEV)
+        d = _desc(a_dev=ad, w_dev=wdq_, w_scale_dev=scd, slab_dev=slab, M=M, N=1024, K=Kd, epilogue=4, prompt_form=prompt)
+        call(capi, "t3_op_gemm_ex", C.byref(d), None)
+        torch.cuda.synchronize()
+        assert torch.allclose(slab.sum(0), ad.float() @ deq.T, rtol=1e-4, atol=1e-4), f"int8 slab K={Kd}"
+    # q|k|v + RoPE + cache write
+    cfg = T3ModelConfig.english()
+    wqkv = _rand((3 * H * hd, K), 85, 0.03).to(DEV)
+    wq3, sc3 = _quantized(capi, wqkv)
+    deq3 = (W.quantize_int8(wqkv.cpu())[0].float() * sc3.cpu()[:, None]).to(DEV)
+    rope = W.rope_table(cfg, 1000).to(DEV)
+    pool, bt, layer_stride = _kv_setup(1, 16, 1)
+    pos = torch.randperm(1000, generator=torch.Generator().manual_seed(86))[:M].to(torch.int32)
+    posd, std, btd = pos.to(DEV), torch.zeros(M, dtype=torch.int32, device=DEV), bt.to(DEV)
+    qkv = torch.zeros(M, 3 * H * hd, dtype=torch.bfloat16, device=DEV)
+    d = _desc(a_dev=a, w_dev=wq3, w_scale_dev=sc3, out_dev=qkv, M=M, N=3 * H * hd, K=K, epilogue=3, prompt_form=prompt,
+              H=H, hd=hd, layer=0, max_pages=16, rope_dev=rope, pos_dev=posd, stream_dev=std, kv_pool_dev=pool,
+              layer_stride_elems=layer_stride, block_table_dev=btd)
+    call(capi, "t3_op_gemm_ex", C.byref(d), None)
+    torch.cuda.synchronize()
+    r3 = r16(a.float() @ deq3.T).cpu()
+    cs = rope.float().cpu()[pos.long()]
+    cos, sin = cs[:, None, :32], cs[:, None, 32:]
+    for lo, name in ((0, "q"), (1024, "k")):
+        t = r3[:, lo:lo + 1024].view(M, H, hd)
+        x, y = t[..., :32], t[..., 32:]
+        want = torch.cat([x * cos - y * sin, y * cos + x * sin], -1).reshape(M, H * hd)
+        mag = torch.cat([torch.maximum(x.abs(), y.abs())] * 2, -1).reshape(M, H * hd)
+        assert_bf16_close(qkv[:, lo:lo + 1024], want, mag=mag, ulps=2.5, max_frac=0.04, what="int8 " + name)
+    assert_bf16_close(qkv[:, 2048:], r3[:, 2048:], what="int8 v")
+    v = pool.cpu().view(-1, 2, H, 64, hd)
+    for r in range(M):
+        pg = int(bt[0, int(pos[r]) // 64])
+        assert torch.equal(v[pg, 0, :, int(pos[r]) % 64, :].reshape(-1), qkv[r, 1024:2048].cpu())
+        assert torch.equal(v[pg, 1, :, int(pos[r]) % 64, :].reshape(-1), qkv[r, 2048:].cpu())

@@ -149,6 +149,9 @@ def main():
     ap.add_argument("--concurrency", type=int, default=0, help="requests decoded together per job (default 32; single: 1)")
     ap.add_argument("--quantization", choices=["none", "int8"], default="none")
     ap.add_argument("--repeat-job", type=int, default=1, help="queue the request list this many times per step")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="collective backend under torchrun; gloo (CPU tensors, ranks may share a GPU) rehearses the "
+                         "multi-rank path on a box with fewer GPUs than ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -160,9 +163,14 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "gloo":
+            local_rank %= max(1, torch.cuda.device_count())
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    coll_dev = torch.device("cpu") if args.backend == "gloo" else torch.device("cuda", local_rank)
 
     single = args.workload == "single"
     paired = not single
@@ -174,7 +182,7 @@ def main():
     if dist is not None:
         # rank 0's checkpoint is the checkpoint: one RCCL broadcast of the weights over xGMI
         from chatterbox_vllm_amd.sharding import broadcast_state_dict
-        sd = broadcast_state_dict(sd, src=0, device=torch.device("cuda", local_rank))
+        sd = broadcast_state_dict(sd, src=0, device=coll_dev)
     conds = [W.synthetic_cond_emb(v) for v in range(4)]
     job = build_job(seed=7 + rank, n_requests=args.requests, workload=args.workload, repeat=args.repeat_job)
     eng = T3Engine(cfg, sd, max_model_len=MAX_MODEL_LEN, max_num_seqs=conc, cfg_scale=CFG_SCALE,
@@ -199,15 +207,15 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], device=f"cuda:{local_rank}", dtype=torch.float64)
+        t = torch.tensor([dt], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        tk = torch.tensor([tokens], device=f"cuda:{local_rank}", dtype=torch.int64)
+        tk = torch.tensor([tokens], device=coll_dev, dtype=torch.int64)
         dist.all_reduce(tk, op=dist.ReduceOp.SUM)
         total_tokens = int(tk.item())
         # the job's result travels to rank 0 the way a sharded generate() returns it
         from chatterbox_vllm_amd.sharding import gather_token_ids
-        gathered = gather_token_ids(last_ids, device=torch.device("cuda", local_rank))
+        gathered = gather_token_ids(last_ids, device=coll_dev)
         assert rank != 0 or len(gathered) == world * len(job)
     else:
         total_tokens = tokens

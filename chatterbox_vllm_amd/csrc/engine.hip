@@ -156,6 +156,7 @@ struct t3_engine {
     bool async_steps = true;
 
     std::deque<std::unique_ptr<Request>> waiting;
+    int schedule_policy = 0;                            // 0: first come first served; 1: longest expected request first
     std::vector<std::unique_ptr<Request>> slots;
 
     std::unordered_map<int, hipGraphExec_t> graphs;
@@ -757,7 +758,23 @@ extern "C" int t3_engine_add_request(t3_engine* e, int64_t req_id, const int32_t
     r->prompt_len = P;
     r->limit = std::max(1, std::min(sp->max_tokens, c.max_model_len - P));
     r->reserve_pages = pages_for(std::min(P + sp->max_tokens, c.max_model_len));
-    e->waiting.push_back(std::move(r));
+    if (e->schedule_policy == 1) {
+        // longest first: a queue that is known up front drains with fewer half-empty steps at its end.  Stable
+        // for equal sizes; which requests share a step never changes a request's tokens.
+        const int work = r->prompt_len + r->limit;
+        auto it = e->waiting.begin();
+        while (it != e->waiting.end() && (*it)->prompt_len + (*it)->limit >= work) ++it;
+        e->waiting.insert(it, std::move(r));
+    } else {
+        e->waiting.push_back(std::move(r));
+    }
+    return 0;
+}
+
+extern "C" int t3_engine_set_schedule_policy(t3_engine* e, int32_t policy) {
+    T3_REQUIRE(e, "null argument");
+    T3_REQUIRE(policy == 0 || policy == 1, "policy must be 0 (first come first served) or 1 (longest first)");
+    e->schedule_policy = policy;
     return 0;
 }
 

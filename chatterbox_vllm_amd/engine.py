@@ -78,7 +78,7 @@ class T3Engine:
                  max_model_len: int = 1000, max_num_seqs: int = 32, cfg_scale: Optional[float] = None,
                  cfg_paired: Optional[bool] = None, device: int = 0, enforce_eager: bool = False,
                  kv_pages: int = 0, max_prefill_rows: int = 2048, quantization: Optional[str] = None,
-                 **_ignored_vllm_kwargs):
+                 scheduling_policy: str = "fcfs", **_ignored_vllm_kwargs):
         if cfg_scale is None:                      # models/t3/t3.py:343
             cfg_scale = float(os.environ.get("CHATTERBOX_CFG_SCALE", "0.5"))
         if cfg_paired is None:
@@ -104,6 +104,10 @@ class T3Engine:
             kv_pages=int(kv_pages))
         self._h = C.c_void_p()
         _capi.check(self._lib, self._lib.t3_engine_create(C.byref(cfg), C.byref(self._h)))
+        if scheduling_policy not in ("fcfs", "longest_first"):
+            raise ValueError("scheduling_policy must be 'fcfs' (vLLM's default) or 'longest_first'")
+        self.scheduling_policy = scheduling_policy
+        _capi.check(self._lib, self._lib.t3_engine_set_schedule_policy(self._h, int(scheduling_policy == "longest_first")))
         self._next_id = 0
         self._load(state_dict)
 

@@ -98,6 +98,11 @@ int t3_engine_add_request(t3_engine* e, int64_t req_id, const int32_t* text_ids,
  * cap >= 2 * max_num_seqs and loop while t3_engine_has_unfinished(). */
 int t3_engine_step(t3_engine* e, int64_t* out_req_ids, int32_t* out_tokens, int32_t* out_finished,
                    int32_t cap, int32_t* n_out);
+/* Admission order of waiting requests: 0 = first come first served (vLLM's default policy, what the reference
+ * runs under, tts.py:130-140); 1 = longest first by prompt + max_tokens, which shortens the half-empty tail of a
+ * queue that is known up front (one generate() call).  Applies to requests added afterwards; a request's tokens
+ * do not depend on what it shares a step with. */
+int t3_engine_set_schedule_policy(t3_engine* e, int32_t policy);
 int t3_engine_abort(t3_engine* e, int64_t req_id);
 int t3_engine_has_unfinished(t3_engine* e);
 int t3_engine_get_stats(t3_engine* e, t3_step_stats* out);

@@ -129,8 +129,9 @@ def test_ids_do_not_depend_on_batch_or_scheduling(small):
     sps = [SamplingParams(temperature=0.0, repetition_penalty=2.0, max_tokens=m, stop_token_ids=[STOP]) for m in lens]
     items = _items(texts, voices)
 
-    def run(max_num_seqs, eager, sel=None):
-        eng = T3Engine(cfg, sd, max_model_len=256, max_num_seqs=max_num_seqs, cfg_scale=3.0, enforce_eager=eager)
+    def run(max_num_seqs, eager, sel=None, policy="fcfs"):
+        eng = T3Engine(cfg, sd, max_model_len=256, max_num_seqs=max_num_seqs, cfg_scale=3.0, enforce_eager=eager,
+                       scheduling_policy=policy)
         idx = list(range(10)) if sel is None else sel
         outs = eng.generate([items[i] for i in idx], [sps[i] for i in idx])
         eng.shutdown()
@@ -140,6 +141,7 @@ def test_ids_do_not_depend_on_batch_or_scheduling(small):
     assert [len(x) for x in base] == lens and fin == ["length"] * 10
     assert run(16, False)[0] == base                        # HIP graph replay
     assert run(3, False)[0] == base                         # continuous batching, 3 slots
+    assert run(3, False, policy="longest_first")[0] == base # another admission order, results in input order
     for i in (0, 4, 7):
         assert run(1, True, [i])[0][0] == base[i]           # alone
 

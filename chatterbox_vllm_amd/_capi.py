@@ -82,6 +82,11 @@ SIGNATURES = {
     "t3_kernel_class_name": ([C.c_int32], C.c_char_p),
     "t3_engine_get_kernel_times": ([_P, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                     C.c_int32], C.c_int),
+    "t3_condenc_create": ([C.c_int32, C.POINTER(_P)], C.c_int),
+    "t3_condenc_load_tensor": ([_P, C.c_char_p, C.POINTER(C.c_float), C.POINTER(C.c_int64), C.c_int32], C.c_int),
+    "t3_condenc_encode": ([_P, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int32, C.c_float, C.POINTER(C.c_float)], C.c_int),
+    "t3_condenc_emotion_row": ([_P, C.c_float, C.POINTER(C.c_float)], C.c_int),
+    "t3_condenc_destroy": ([_P], C.c_int),
     "t3_engine_set_keep_logits": ([_P, C.c_int32], C.c_int),
     "t3_engine_last_logits": ([_P, C.c_int64, C.POINTER(C.c_float)], C.c_int),
     "t3_op_repack_weight": ([_P, _P, C.c_int32, C.c_int32, _P], C.c_int),

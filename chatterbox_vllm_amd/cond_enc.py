@@ -1,23 +1,25 @@
 """Conditioning prefix: (speaker embedding, 150 prompt-speech embeddings, emotion scalar) -> [34, 1024].
 
-Host-side fp32 restatement of the reference's ``T3CondEnc`` + ``Perceiver``
-(src/chatterbox_vllm/models/t3/modules/cond_enc.py:57-123, perceiver.py:116-215): it runs once
-per voice and its result is cached by the caller, so it is not on the per-token path.
+The reference's ``T3CondEnc`` + ``Perceiver`` (src/chatterbox_vllm/models/t3/modules/cond_enc.py:57-123,
+perceiver.py:116-215) run as fp32 HIP kernels in ``libt3hip.so`` (csrc/condenc.hip) behind the
+``t3_condenc_*`` entry points; this module loads the ``cond_enc.*`` checkpoint tensors into that
+encoder and calls it.  It runs once per voice and the caller caches the result
+(``get_audio_conditionals``), so it is not on the per-token path.
 
   row 0       spkr_enc(speaker_emb)                     Linear 256 -> 1024
   rows 1..32  perceiver(prompt embeddings)              32 learned queries cross-attend to the prompt,
                                                         then self-attend, through ONE shared block
                                                         (LayerNorm, biased q/k/v/out Linears, 4 heads x 256)
   row 33      emotion_adv_fc(exaggeration)              Linear 1 -> 1024, no bias
-
-Weights use the checkpoint names with the ``cond_enc.`` prefix removed.
 """
 from __future__ import annotations
 
+import ctypes as C
 from typing import Dict
 
 import torch
-import torch.nn.functional as F
+
+from . import _capi
 
 N_QUERIES, N_HEADS, DIM, SPK = 32, 4, 1024, 256
 
@@ -48,30 +50,46 @@ def synthetic_weights(seed: int = 1234) -> Dict[str, torch.Tensor]:
     return out
 
 
-def _attention_block(w: Dict[str, torch.Tensor], x1: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
-    """x1 + proj_out(attention(q(norm x1), k(norm x2), v(norm x2)))   (perceiver.py:159-173)."""
-    p = "perceiver.attn."
-    ln = lambda x: F.layer_norm(x, (DIM,), w[p + "norm.weight"], w[p + "norm.bias"])
-    lin = lambda x, n: F.linear(x, w[p + n + ".weight"], w[p + n + ".bias"])
-    n1, n2 = ln(x1), ln(x2)
-    split = lambda t: t.view(t.shape[0], N_HEADS, DIM // N_HEADS).permute(1, 0, 2)
-    q, k, v = split(lin(n1, "to_q")), split(lin(n2, "to_k")), split(lin(n2, "to_v"))
-    att = torch.softmax(q @ k.transpose(1, 2) * (DIM // N_HEADS) ** -0.5, dim=-1) @ v
-    att = att.permute(1, 0, 2).reshape(x1.shape[0], DIM)
-    return x1 + lin(att, "proj_out")
+def _fptr(t: torch.Tensor):
+    return C.cast(_capi.ptr(t), C.POINTER(C.c_float))
 
 
-def emotion_row(w: Dict[str, torch.Tensor], exaggeration: float) -> torch.Tensor:
-    return (w["emotion_adv_fc.weight"].float() * float(exaggeration)).reshape(DIM)
+class CondEncoder:
+    """The GPU conditioning encoder of one checkpoint.  ``weights``: name (without ``cond_enc.``) -> tensor."""
 
+    def __init__(self, weights: Dict[str, torch.Tensor], device: int = 0):
+        self._lib = _capi.load()
+        self._h = C.c_void_p()
+        _capi.check(self._lib, self._lib.t3_condenc_create(int(device), C.byref(self._h)))
+        missing = [n for n in _SHAPES if n not in weights]
+        if missing:
+            raise KeyError(f"checkpoint is missing cond_enc tensors: {missing[:3]}")
+        for name in _SHAPES:
+            t = weights[name].detach().to(device="cpu", dtype=torch.float32).contiguous()
+            shape = (C.c_int64 * t.dim())(*t.shape)
+            _capi.check(self._lib, self._lib.t3_condenc_load_tensor(self._h, name.encode(), _fptr(t), shape, t.dim()))
 
-@torch.no_grad()
-def encode(w: Dict[str, torch.Tensor], speaker_emb: torch.Tensor, prompt_emb: torch.Tensor,
-           exaggeration: float = 0.5) -> torch.Tensor:
-    """speaker_emb [256] (any shape with 256 elements), prompt_emb [n, 1024] -> fp32 [34, 1024]."""
-    w = {k: v.float() for k, v in w.items()}
-    spk = F.linear(speaker_emb.float().reshape(SPK), w["spkr_enc.weight"], w["spkr_enc.bias"])[None]
-    q = w["perceiver.pre_attention_query"][0]
-    pre = _attention_block(w, q, prompt_emb.float())
-    res = _attention_block(w, pre, pre)
-    return torch.cat([spk, res, emotion_row(w, exaggeration)[None]], 0)
+    def encode(self, speaker_emb: torch.Tensor, prompt_emb: torch.Tensor, exaggeration: float = 0.5) -> torch.Tensor:
+        """speaker_emb: 256 values (any shape), prompt_emb [n, 1024] -> fp32 [34, 1024] on the CPU."""
+        spk = speaker_emb.detach().to(device="cpu", dtype=torch.float32).reshape(SPK).contiguous()
+        pe = prompt_emb.detach().to(device="cpu", dtype=torch.float32).reshape(-1, DIM).contiguous()
+        out = torch.empty(N_QUERIES + 2, DIM, dtype=torch.float32)
+        _capi.check(self._lib, self._lib.t3_condenc_encode(self._h, _fptr(spk), _fptr(pe), pe.shape[0],
+                                                          C.c_float(float(exaggeration)), _fptr(out)))
+        return out
+
+    def emotion_row(self, exaggeration: float) -> torch.Tensor:
+        out = torch.empty(DIM, dtype=torch.float32)
+        _capi.check(self._lib, self._lib.t3_condenc_emotion_row(self._h, C.c_float(float(exaggeration)), _fptr(out)))
+        return out
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.t3_condenc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

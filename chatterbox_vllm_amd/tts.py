@@ -80,6 +80,7 @@ class ChatterboxTTS:
         self._speech_emb = speech_emb
         self._speech_pos_emb = speech_pos_emb
         self._synthetic_voices = default_conds is None
+        self._cond_encoder: Optional[_cond_enc.CondEncoder] = None
         self.last_t3_seconds = 0.0
         self.last_request_outputs: List[RequestOutput] = []
 
@@ -158,6 +159,13 @@ class ChatterboxTTS:
         return cls._build(sd, cfg, tokenizer, variant=variant, **kwargs)
 
     # ---- conditioning ---------------------------------------------------------------------
+    def _encoder(self) -> "_cond_enc.CondEncoder":
+        if self.cond_enc_weights is None:
+            raise RuntimeError("checkpoint has no cond_enc.* weights")
+        if self._cond_encoder is None:
+            self._cond_encoder = _cond_enc.CondEncoder(self.cond_enc_weights, device=self.t3.device)
+        return self._cond_encoder
+
     def get_supported_languages(self) -> Dict[str, str]:
         return SUPPORTED_LANGUAGES.copy() if self.variant == "multilingual" else {"en": "English"}
 
@@ -175,16 +183,14 @@ class ChatterboxTTS:
         t3c = self.default_conds["t3"]
         tokens = torch.atleast_2d(t3c["cond_prompt_speech_tokens"]).long()
         emb = self._speech_emb[tokens[0]] + self._speech_pos_emb[: tokens.shape[1]]       # tts.py:238
-        cond = _cond_enc.encode(self.cond_enc_weights, t3c["speaker_emb"].float(), emb, 0.5)
+        cond = self._encoder().encode(t3c["speaker_emb"].float(), emb, 0.5)
         return self.default_conds.get("gen", {}), cond.to("cpu")
 
     def update_exaggeration(self, cond_emb: torch.Tensor, exaggeration: float) -> torch.Tensor:
         if exaggeration == 0.5:
             return cond_emb
-        if self.cond_enc_weights is None:
-            raise RuntimeError("checkpoint has no cond_enc.emotion_adv_fc weights")
         out = cond_emb.clone()
-        out[-1] = _cond_enc.emotion_row(self.cond_enc_weights, exaggeration)
+        out[-1] = self._encoder().emotion_row(exaggeration)
         return out
 
     # ---- generation -----------------------------------------------------------------------
@@ -250,6 +256,9 @@ class ChatterboxTTS:
         return results
 
     def shutdown(self):
+        if self._cond_encoder is not None:
+            self._cond_encoder.close()
+            self._cond_encoder = None
         if self.t3 is not None:
             self.t3.shutdown()
         self.t3 = None

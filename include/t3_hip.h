@@ -123,6 +123,22 @@ const char* t3_kernel_class_name(int32_t cls);
  * total milliseconds, launches, and algorithmic bytes (weights or KV a launch must read). */
 int t3_engine_get_kernel_times(t3_engine* e, int32_t phase, double* ms, int64_t* launches, int64_t* bytes, int32_t n);
 
+/* ---- conditioning encoder: the reference's T3CondEnc + Perceiver
+ *      (src/chatterbox_vllm/models/t3/modules/cond_enc.py:57-123, perceiver.py:116-215) as fp32 HIP kernels.
+ *      Called once per voice from get_audio_conditionals (tts.py:215-247) and for the emotion row of
+ *      update_exaggeration (tts.py:249-257).  All pointers are host memory, fp32. ----------------------- */
+typedef struct t3_condenc t3_condenc;
+int t3_condenc_create(int32_t device, t3_condenc** out);
+/* `name` is the checkpoint tensor name without the "cond_enc." prefix (spkr_enc.weight, spkr_enc.bias,
+ * emotion_adv_fc.weight, perceiver.pre_attention_query, perceiver.attn.{norm,to_q,to_k,to_v,proj_out}.{weight,bias}). */
+int t3_condenc_load_tensor(t3_condenc* c, const char* name, const float* data, const int64_t* shape, int32_t ndim);
+/* speaker_emb [256], prompt_emb [n_prompt, 1024] (speech_emb[tokens] + speech_pos_emb[:n], tts.py:238),
+ * out [34, 1024]: row 0 speaker, rows 1..32 perceiver, row 33 emotion_adv_fc(exaggeration).  Blocking. */
+int t3_condenc_encode(t3_condenc* c, const float* speaker_emb, const float* prompt_emb, int32_t n_prompt,
+                      float exaggeration, float* out);
+int t3_condenc_emotion_row(t3_condenc* c, float exaggeration, float* out);
+int t3_condenc_destroy(t3_condenc* c);
+
 /* ---- debugging taps for parity tests ------------------------------------------- */
 /* Keep the CFG-combined, penalised fp32 logits of every sampled token (turns graph replay
  * off).  The logits are what models/t3/t3.py:725-739 returns, after the sampler's

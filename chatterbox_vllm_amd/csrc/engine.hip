@@ -544,7 +544,9 @@ extern "C" int t3_engine_create(const t3_config* cfg, t3_engine** out) {
     T3_REQUIRE(cfg->n_layers >= 1 && cfg->max_num_seqs >= 1 && cfg->max_model_len >= kCondRows + 3, "bad sizes");
     T3_REQUIRE(cfg->speech_vocab + kOffset <= kSeenStride, "speech vocab too large");
     T3_HIP_CHECK(hipSetDevice(cfg->device));
-    std::unique_ptr<t3_engine> e(new t3_engine());
+    // a construction that fails half-way gives back what it had allocated
+    struct Destroy { void operator()(t3_engine* p) const { (void)t3_engine_destroy(p); } };
+    std::unique_ptr<t3_engine, Destroy> e(new t3_engine());
     e->cfg = *cfg;
     if (e->cfg.max_prefill_rows < e->cfg.max_model_len) e->cfg.max_prefill_rows = e->cfg.max_model_len;
     const t3_config& c = e->cfg;

@@ -291,3 +291,42 @@ def test_int8_weights_follow_the_dequantised_oracle_and_stay_near_bf16(small):
         assert (a[0][fin] - b[0][fin]).abs().max().item() <= 0.25
     with pytest.raises(ValueError):
         T3Engine(cfg, sd, quantization="fp4")
+
+
+def test_small_kv_pool_and_prompt_row_budget_only_delay_requests(small):
+    """KV allocator and admission limits: a pool that holds two full-length requests, a prompt-row budget of
+    one prompt per step and a prompt that fills max_model_len to the last position.  Requests wait (never
+    fail, never preempt), ids equal the unconstrained run, and every page is back in the pool at the end."""
+    cfg, sd = small
+    max_len = 192                                           # 3 pages per stream
+    texts = [_text(n, 600 + n) for n in (3, 50, 11, 90, 25, 7)] + [_text(max_len - 34 - 1 - 2 - 1, 699)]
+    voices = [i % 3 for i in range(len(texts))]
+    lens = [40, 30, 64, 20, 50, 33, 5]                      # the last prompt is max_len - 1 long: one token fits
+    sps = [SamplingParams(temperature=0.0, repetition_penalty=2.0, max_tokens=m, stop_token_ids=[STOP]) for m in lens]
+    items = _items(texts, voices)
+    assert len(build_prompt_ids(texts[-1])) == max_len - 1
+
+    free = T3Engine(cfg, sd, max_model_len=max_len, max_num_seqs=8, cfg_scale=3.0)
+    base = free.generate(items, sps)
+    free.shutdown()
+    assert [len(o.outputs[0].token_ids) for o in base] == [40, 30, 64, 20, 50, 33, 1]
+    assert base[-1].outputs[0].finish_reason == "length"
+
+    pool = 2 * 2 * 3                                        # two requests x two streams x three pages
+    eng = T3Engine(cfg, sd, max_model_len=max_len, max_num_seqs=8, cfg_scale=3.0, kv_pages=pool, max_prefill_rows=max_len)
+    seen_waiting, max_running = 0, 0
+
+    def watch(e):
+        nonlocal seen_waiting, max_running
+        st = e.stats()
+        seen_waiting = max(seen_waiting, st.waiting)
+        max_running = max(max_running, st.running)
+        assert 0 <= st.free_pages <= pool
+
+    outs = eng.generate(items, sps, on_step=watch)
+    assert [o.outputs[0].token_ids for o in outs] == [o.outputs[0].token_ids for o in base]
+    assert seen_waiting > 0 and max_running <= 3            # the pool, not the slot count, limited concurrency
+    assert eng.stats().free_pages == pool and not eng.has_unfinished()
+    with pytest.raises(Exception):                          # a pool that cannot hold one full request is refused
+        T3Engine(cfg, sd, max_model_len=max_len, max_num_seqs=2, cfg_scale=3.0, kv_pages=5)
+    eng.shutdown()

@@ -1,0 +1,104 @@
+"""The public facade on the GPU: the three prompts of the reference's example-tts.py (BASELINE config 1) through
+``ChatterboxTTS.generate`` and one French prompt through ``ChatterboxMultilingualTTS.generate``, on a seeded
+2-layer checkpoint.  Tokenisation comes from the ids the reference's own vocabularies produced for these very
+prompts (tests/golden/ref_text_fixture.json), so the test needs no vocabulary file.
+
+Checked: the request the facade builds (prompt string, ids, batch-wide max_tokens, sampling clamp), results in
+input order, the facade's tensors == post-processing of the engine's ids, and the engine's ids against the oracle
+(same bar as tests/test_engine_gpu.py)."""
+import json
+import os
+
+import pytest
+import torch
+
+from chatterbox_vllm_amd import weights as W
+from chatterbox_vllm_amd.text_utils import batch_max_tokens
+from chatterbox_vllm_amd.tts import ChatterboxTTS, postprocess_speech_ids, STOP_OFFSET_ID
+from chatterbox_vllm_amd.mtl_tts import ChatterboxMultilingualTTS
+from oracle.t3_oracle import T3Oracle, SamplingSpec
+
+pytestmark = pytest.mark.gpu
+
+EXAMPLE_PROMPTS = [
+    "You are listening to a demo of the Chatterbox TTS model running on VLLM.",
+    "This is a separate prompt to test the batching implementation.",
+    "And here is a third prompt. It's a bit longer than the first one, but not by much.",
+]
+
+
+@pytest.fixture(scope="module")
+def text_fx(golden_dir):
+    with open(os.path.join(golden_dir, "ref_text_fixture.json")) as f:
+        return json.load(f)
+
+
+def _lookup_tokenizer(pairs):
+    table = {s: ids for s, ids in pairs}
+
+    def tok(prompt, **kw):
+        return table[prompt]
+    return tok
+
+
+def _oracle_ok(oracle, ids, text, cond, cfg_scale, max_model_len):
+    r = oracle.generate_one(text, cond, SamplingSpec(max_tokens=len(ids)), max_model_len=max_model_len, forced=ids,
+                            return_logits=True)
+    tol = 2 * (1 + 2 * cfg_scale) * 2 ** -5
+    for t, tok in enumerate(ids):
+        L = r["logits"][t]
+        assert L[tok].item() >= L.max().item() - tol, f"step {t}: id {tok} is not the oracle's choice"
+
+
+def test_example_prompts_through_chatterbox_tts(text_fx, monkeypatch):
+    monkeypatch.setenv("CHATTERBOX_DETERMINISTIC", "1")            # tts.py:358-362: temperature 0, top_p 1
+    monkeypatch.setenv("CHATTERBOX_CFG_SCALE", "0.5")
+    tts = ChatterboxTTS.from_synthetic(tokenizer=_lookup_tokenizer(text_fx["en"]), n_layers=2, max_model_len=400,
+                                       max_batch_size=3)
+    assert tts.sr == 24000 and tts.get_supported_languages() == {"en": "English"}
+    out = tts.generate(EXAMPLE_PROMPTS, max_tokens=48)
+    assert len(out) == 3 and all(o.dtype == torch.int64 and o.dim() == 1 for o in out)
+    ros = tts.last_request_outputs
+    assert [ro.prompt for ro in ros] == [s for s, _ in text_fx["en"]]                   # "[START]...[STOP]", input order
+    assert [ro.prompt_token_ids for ro in ros] == [ids for _, ids in text_fx["en"]]
+    cap = batch_max_tokens([ro.prompt for ro in ros], 48, 400)
+    assert cap == 48 and all(len(ro.outputs[0].token_ids) <= cap for ro in ros)
+    for o, ro in zip(out, ros):
+        assert torch.equal(o, postprocess_speech_ids(ro.outputs[0].token_ids, ro.prompt))
+        assert int(o.max()) < 6561 if o.numel() else True
+    cond = tts.get_audio_conditionals(None)[1]
+    oracle = T3Oracle(W.synthetic_state_dict(tts.t3_config), n_layers=2, cfg_scale=0.5)
+    _oracle_ok(oracle, ros[1].outputs[0].token_ids[:24], ros[1].prompt_token_ids, cond, 0.5, 400)
+    # one prompt as a plain string; an unsupported language is refused (tts.py:317-322)
+    one = tts.generate(EXAMPLE_PROMPTS[1], max_tokens=48)
+    assert len(one) == 1 and torch.equal(one[0], out[1])
+    with pytest.raises(ValueError):
+        tts.generate(EXAMPLE_PROMPTS[0], language_id="fr")
+    tts.shutdown()
+
+
+def test_french_prompt_through_multilingual_tts(text_fx, monkeypatch):
+    monkeypatch.setenv("CHATTERBOX_DETERMINISTIC", "1")
+    monkeypatch.setenv("CHATTERBOX_CFG_SCALE", "0.5")
+    (s, ids), = text_fx["mtl_fr"]
+    seen = {}
+
+    def tok(prompt, language_id=None, **kw):                         # mtl_tts.py:423-435: "[fr]" prefix + hint
+        seen["prompt"], seen["lang"] = prompt, language_id
+        return ids
+    tts = ChatterboxMultilingualTTS.from_synthetic(tokenizer=tok, n_layers=2, max_model_len=400, max_batch_size=2)
+    assert "fr" in tts.get_supported_languages() and len(tts.get_supported_languages()) == 23
+    out = tts.generate("Bonjour, comment ça va? Ceci est le modèle de synthèse vocale multilingue Chatterbox.",
+                       language_id="fr", max_tokens=30)
+    assert seen == {"prompt": "[fr]" + s, "lang": "fr"}
+    ro = tts.last_request_outputs[0]
+    assert ro.prompt_token_ids == ids and ids[0] == text_fx["mtl_special_ids"]["[fr]"]
+    assert torch.equal(out[0], postprocess_speech_ids(ro.outputs[0].token_ids, ro.prompt))
+    cond = tts.get_audio_conditionals(None)[1]
+    oracle = T3Oracle(W.synthetic_state_dict(tts.t3_config), n_layers=2, cfg_scale=0.5)
+    _oracle_ok(oracle, ro.outputs[0].token_ids[:20], ids, cond, 0.5, 400)
+    with pytest.raises(ValueError):
+        tts.generate(["a", "b"], language_id=["fr"])                 # mtl_tts.py:412-413
+    with pytest.raises(ValueError):
+        tts.generate("a", language_id="xx")
+    tts.shutdown()

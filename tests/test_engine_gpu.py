@@ -330,3 +330,41 @@ def test_small_kv_pool_and_prompt_row_budget_only_delay_requests(small):
     with pytest.raises(Exception):                          # a pool that cannot hold one full request is refused
         T3Engine(cfg, sd, max_model_len=max_len, max_num_seqs=2, cfg_scale=3.0, kv_pages=5)
     eng.shutdown()
+
+
+def test_full_size_job_rows_do_not_depend_on_the_batch():
+    """BASELINE's full sizes (30 layers, 32 CFG-paired slots, contexts up to max_model_len 1000) are out of the
+    CPU oracle's reach, so the property checked here is size-independent: a request's ids inside the loaded
+    engine (64 decode rows, 16 KV pages per stream, either admission order, graph replay, pipelined steps) are
+    bit-identical to its ids when it runs alone and eagerly.  Together with the oracle parity of the same
+    kernels at small sizes this pins the full-size result."""
+    import bench
+    cfg = T3ModelConfig.english()
+    sd = W.synthetic_state_dict(cfg)
+    job = bench.build_job(seed=7, n_requests=48)
+    job[5] = (job[5][0], 1000 - (34 + len(job[5][0]) + 1), 0)          # one request runs to the last position
+    conds = [W.synthetic_cond_emb(v) for v in range(4)]
+
+    def run(sel, slots, policy, eager=False):
+        eng = T3Engine(cfg, sd, max_model_len=1000, max_num_seqs=slots, cfg_scale=3.0, scheduling_policy=policy,
+                       enforce_eager=eager)
+        rids = [eng.add_request(job[i][0], conds[job[i][2]],
+                                SamplingParams(temperature=0.0, repetition_penalty=2.0, max_tokens=job[i][1])) for i in sel]
+        out = {r: [] for r in rids}
+        peak = 0
+        while eng.has_unfinished():
+            for rid, tok, _ in eng.step():
+                out[rid].append(tok)
+            peak = max(peak, eng.stats().decode_rows)
+        eng.shutdown()
+        return [out[r] for r in rids], peak
+
+    full, peak = run(range(48), 32, "longest_first")
+    assert peak == 64 and [len(x) for x in full] == [j[1] for j in job]
+    assert len(full[5]) + 34 + len(job[5][0]) + 1 == 1000
+    fcfs, _ = run(range(48), 32, "fcfs")
+    assert fcfs == full
+    lens = [len(x) for x in full]
+    for i in (5, lens.index(min(lens)), 17):
+        alone, _ = run([i], 1, "fcfs", eager=True)
+        assert alone[0] == full[i], f"request {i} differs between the loaded engine and a run alone"

@@ -281,7 +281,7 @@ def main():
         result["kernel_breakdown"]["event_timed_pass_s"] = round(timed_pass, 3)
     eng.shutdown()
 
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:          # the CPU leg is timed on the one-GPU run only
         cb, cpu_ids, sub = cpu_baseline(cfg, sd, job, conds, paired=paired)
         result["cpu_baseline"] = cb
     if rank == 0:

@@ -59,6 +59,7 @@ class T3GemmDesc(C.Structure):
         ("H", C.c_int32), ("hd", C.c_int32), ("layer", C.c_int32), ("max_pages", C.c_int32),
         ("rope_dev", C.c_void_p), ("pos_dev", C.c_void_p), ("stream_dev", C.c_void_p), ("kv_pool_dev", C.c_void_p),
         ("layer_stride_elems", C.c_int64), ("block_table_dev", C.c_void_p),
+        ("a_tiled", C.c_int32), ("out_tiled", C.c_int32),
     ]
 
 
@@ -95,6 +96,7 @@ SIGNATURES = {
     "t3_op_gemm_slab": ([_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P], C.c_int),
     "t3_op_slab_split": ([], C.c_int),
     "t3_op_slab_add_rmsnorm": ([_P, C.c_int32, _P, _P, _P, C.c_int32, C.c_int32, C.c_float, _P], C.c_int),
+    "t3_op_slab_add_rmsnorm_tiled": ([_P, C.c_int32, _P, _P, _P, C.c_int32, C.c_int32, C.c_float, _P], C.c_int),
     "t3_op_gemm_silu": ([_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P], C.c_int),
     "t3_op_gemm_qkv_rope": ([_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int64,
                              C.c_int32, _P, C.c_int32, _P], C.c_int),

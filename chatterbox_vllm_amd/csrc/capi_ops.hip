@@ -108,6 +108,13 @@ extern "C" int t3_op_gemm_prompt_qkv_rope(const void* a_dev, const void* wt_dev,
                   layer, block_table_dev, max_pages, stream);
 }
 
+extern "C" int t3_op_slab_add_rmsnorm_tiled(const float* slab_dev, int32_t nsplit, void* res_dev, const void* w_dev,
+                                            void* xn_dev, int32_t rows, int32_t d, float eps, void* stream) {
+    T3_REQUIRE(res_dev && w_dev && xn_dev, "null argument");
+    return launch_slab_add_rmsnorm(slab_dev, nsplit, static_cast<bf16_t*>(res_dev), static_cast<const bf16_t*>(w_dev),
+                                   static_cast<bf16_t*>(xn_dev), rows, d, eps, static_cast<hipStream_t>(stream), true);
+}
+
 extern "C" int t3_op_quantize_weight(const void* w_dev, void* wq_dev, float* scale_dev, int32_t N, int32_t K, void* stream) {
     T3_REQUIRE(w_dev && wq_dev && scale_dev, "null argument");
     return launch_quantize(static_cast<const bf16_t*>(w_dev), static_cast<uint8_t*>(wq_dev), scale_dev, N, K,
@@ -118,11 +125,12 @@ extern "C" int t3_op_gemm_ex(const t3_gemm_desc* d, void* stream) {
     T3_REQUIRE(d && d->a_dev && d->w_dev, "null argument");
     T3_REQUIRE(d->epilogue >= 0 && d->epilogue <= 4, "epilogue must be 0..4");
     T3_REQUIRE(!d->prompt_form || d->epilogue >= 2, "the prompt form exists for epilogues 2, 3 and 4");
+    T3_REQUIRE(!d->prompt_form || (!d->a_tiled && !d->out_tiled), "the prompt form reads and writes row-major activations");
     hipStream_t st = static_cast<hipStream_t>(stream);
     GemmArgs g{};
     g.A = static_cast<const bf16_t*>(d->a_dev); g.lda = d->K; g.Wt = static_cast<const bf16_t*>(d->w_dev);
     g.wscale = d->w_scale_dev; g.C = static_cast<bf16_t*>(d->out_dev); g.M = d->M; g.N = d->N; g.K = d->K;
-    g.slab = d->slab_dev;
+    g.slab = d->slab_dev; g.a_tiled = d->a_tiled != 0; g.c_tiled = d->out_tiled != 0;
     switch (d->epilogue) {
         case 0: case 1:
             T3_REQUIRE(d->out_dev && d->ldc >= 1, "bad output");

@@ -289,15 +289,18 @@ int run_layers(t3_engine* e, int rows, const int32_t* d_pos, const int32_t* d_st
     hipStream_t st = e->stream;
     const KvView kv = e->kvview();
     const long long WB = c.weight_int8 ? 1 : 2;          // bytes per projection weight (algorithmic-bytes accounting)
+    // decode rows: the normalised activations and the MLP hidden rows travel in activation tile order (t3_common.h),
+    // so every projection operand load is 1 KiB of contiguous memory; prompt rows stay row-major for the LDS-tiled kernels
+    const bool tiled = !prefill;
     for (int li = 0; li < c.n_layers; ++li) {
         const Layer& L = e->layers[li];
         // o_proj / down_proj leave split-K partial slabs, folded in by the next norm kernel.  Prompt rows always
         // take the LDS-tiled kernels and decode rows the weight-streaming ones, whatever the row count, so that
         // a row's bits never depend on what shares its launch.
         T3_RUN(e, K_NORM, li, 4LL * rows * D, launch_slab_add_rmsnorm(e->b->slab, li > 0 ? GEMM_SLAB_SPLIT : 0, e->b->res, L.ln1,
-                                                                      e->b->xn, rows, D, c.rms_eps, st));
+                                                                      e->b->xn, rows, D, c.rms_eps, st, tiled));
         GemmArgs g{};
-        g.A = e->b->xn; g.lda = D; g.Wt = L.wqkv; g.wscale = L.sqkv; g.C = e->b->qkv; g.ldc = 3 * D; g.M = rows; g.N = 3 * D; g.K = D;
+        g.A = e->b->xn; g.lda = D; g.a_tiled = tiled; g.Wt = L.wqkv; g.wscale = L.sqkv; g.C = e->b->qkv; g.ldc = 3 * D; g.M = rows; g.N = 3 * D; g.K = D;
         g.n_valid = 3 * D; g.rope = e->rope; g.pos = d_pos; g.row_stream = d_stream; g.kv = kv; g.layer = li;
         T3_RUN(e, K_QKV, li, WB * 3 * D * D, prefill ? launch_gemm_prompt(EPI_QKV_ROPE, g, st) : launch_gemm(EPI_QKV_ROPE, g, st));
         if (prefill) {
@@ -310,24 +313,25 @@ int run_layers(t3_engine* e, int rows, const int32_t* d_pos, const int32_t* d_st
         o.slab = e->b->slab;
         T3_RUN(e, K_OPROJ, li, WB * D * D, prefill ? launch_gemm_prompt(EPI_SLAB, o, st) : launch_gemm_slab(o, st));
         T3_RUN(e, K_NORM, li, 4LL * rows * D, launch_slab_add_rmsnorm(e->b->slab, GEMM_SLAB_SPLIT, e->b->res, L.ln2, e->b->xn, rows, D,
-                                                                      c.rms_eps, st));
+                                                                      c.rms_eps, st, tiled));
         GemmArgs u{};
-        u.A = e->b->xn; u.lda = D; u.Wt = L.wgu; u.wscale = L.sgu; u.C = e->b->hbuf; u.ldc = F; u.M = rows; u.N = 2 * F; u.K = D; u.n_valid = 2 * F;
+        u.A = e->b->xn; u.lda = D; u.a_tiled = tiled; u.c_tiled = tiled; u.Wt = L.wgu; u.wscale = L.sgu; u.C = e->b->hbuf; u.ldc = F; u.M = rows; u.N = 2 * F; u.K = D; u.n_valid = 2 * F;
         T3_RUN(e, K_GATEUP, li, WB * 2 * F * D, prefill ? launch_gemm_prompt(EPI_SILU, u, st) : launch_gemm(EPI_SILU, u, st));
         GemmArgs dn{};
-        dn.A = e->b->hbuf; dn.lda = F; dn.Wt = L.wd; dn.wscale = L.sd; dn.C = e->b->res; dn.ldc = D; dn.M = rows; dn.N = D; dn.K = F; dn.n_valid = D;
+        dn.A = e->b->hbuf; dn.lda = F; dn.a_tiled = tiled; dn.Wt = L.wd; dn.wscale = L.sd; dn.C = e->b->res; dn.ldc = D; dn.M = rows; dn.N = D; dn.K = F; dn.n_valid = D;
         dn.slab = e->b->slab;
         T3_RUN(e, K_DOWN, li, WB * F * D, prefill ? launch_gemm_prompt(EPI_SLAB, dn, st) : launch_gemm_slab(dn, st));
     }
     T3_RUN(e, K_NORM, -1, 4LL * rows * D, launch_slab_add_rmsnorm(e->b->slab, GEMM_SLAB_SPLIT, e->b->res, e->norm_w, e->b->xn, rows, D,
-                                                                  c.rms_eps, st));
+                                                                  c.rms_eps, st, tiled));
     return 0;
 }
 
 int run_head_and_sample(t3_engine* e, t3_engine::Meta& m, int head_rows, const int32_t* d_a_rows, int n_req) {
     const t3_config& c = e->cfg;
     GemmArgs g{};
-    g.A = e->b->xn; g.lda = c.d_model; g.a_rows = d_a_rows; g.Wt = e->head; g.C = e->b->logits; g.ldc = e->head_n;
+    g.A = e->b->xn; g.lda = c.d_model; g.a_rows = d_a_rows; g.a_tiled = d_a_rows == nullptr;   // decode: tile-ordered xn
+    g.Wt = e->head; g.C = e->b->logits; g.ldc = e->head_n;
     g.M = head_rows; g.N = e->head_n; g.K = c.d_model; g.n_valid = e->head_n;
     T3_RUN(e, K_HEAD, -1, 2LL * e->head_n * c.d_model, launch_gemm(EPI_STORE, g, e->stream));
     SampleArgs s{};
@@ -574,7 +578,7 @@ extern "C" int t3_engine_create(const t3_config* cfg, t3_engine** out) {
 
     // activations
     const int prefill_rows = c.max_prefill_rows * e->nstreams_per_req;
-    e->max_rows = std::max(prefill_rows, e->n_streams);
+    e->max_rows = (std::max(prefill_rows, e->n_streams) + 127) / 128 * 128;   // whole row tiles for the tile-ordered buffers
     {
         const size_t R = (size_t)e->max_rows, RD = (size_t)e->n_streams;
         t3_engine::Bufs& b = e->bufs;

@@ -84,12 +84,20 @@ __global__ __launch_bounds__(KW * 64) void gemm_stream_kernel(GemmArgs a) {
     // activation row addresses first: the row gather (head GEMM only) is a dependent load, and a
     // wait for it placed after the weight loads would also wait for the whole HBM stream
     const bf16_t* arow[MT];
+    const int a_step = a.a_tiled ? 512 : 32;         // elements from one k-tile's fragment to the next
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        int r = m0 + mt * 16 + (lane & 15);
-        r = r < a.M ? r : a.M - 1;
-        if constexpr (EPI == EPI_STORE_GATHER) r = a.a_rows[r];
-        arow[mt] = a.A + (size_t)r * a.lda + kt0 * 32 + 8 * (lane >> 4);
+        if (a.a_tiled) {                              // wave-uniform: activation tile order, 1 KiB per fragment
+            int tile = (m0 >> 4) + mt;
+            const int last = (a.M - 1) >> 4;
+            tile = tile < last ? tile : last;
+            arow[mt] = a.A + (((size_t)tile * ktiles + kt0) * 64 + lane) * 8;
+        } else {
+            int r = m0 + mt * 16 + (lane & 15);
+            r = r < a.M ? r : a.M - 1;
+            if constexpr (EPI == EPI_STORE_GATHER) r = a.a_rows[r];
+            arow[mt] = a.A + (size_t)r * a.lda + kt0 * 32 + 8 * (lane >> 4);
+        }
     }
     // QKV epilogue operands (position, rope row, KV page) hang off two levels of dependent loads;
     // fetched here, ahead of and underneath the weight stream, they cost nothing at the end.
@@ -140,7 +148,7 @@ __global__ __launch_bounds__(KW * 64) void gemm_stream_kernel(GemmArgs a) {
     for (int kt = 0; kt < KT; ++kt) {
         bf16x8 af[MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const bf16x8*>(arow[mt] + kt * 32);
+        for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const bf16x8*>(arow[mt] + kt * a_step);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             bf16x8 wv;
@@ -220,7 +228,10 @@ __global__ __launch_bounds__(KW * 64) void gemm_stream_kernel(GemmArgs a) {
                 hv[i] = sg * u;
             }
             u32x2 o = {pack_bf2(hv[0], hv[1]), pack_bf2(hv[2], hv[3])};
-            *reinterpret_cast<u32x2*>(a.C + (size_t)r * F + b * 16 + nl) = o;
+            const int n = b * 16 + nl;
+            const size_t off = a.c_tiled ? ((size_t)(r >> 4) * (F >> 5) + (n >> 5)) * 512 + (((n >> 3) & 3) * 16 + (r & 15)) * 8 + (n & 7)
+                                         : (size_t)r * F + n;
+            *reinterpret_cast<u32x2*>(a.C + off) = o;
         } else {   // EPI_QKV_ROPE
             const int hd = a.kv.hd;                       // 64
             const int D = H * hd;
@@ -365,6 +376,8 @@ int launch_gemm(int epi, const GemmArgs& a, hipStream_t st) {
     T3_REQUIRE(a.M >= 1, "gemm: no rows");
     T3_REQUIRE(a.N % 16 == 0, "gemm: N must be a multiple of 16");
     T3_REQUIRE(a.lda % 8 == 0, "gemm: lda must be a multiple of 8");
+    T3_REQUIRE(!(a.a_tiled && a.a_rows), "gemm: a row gather reads row-major activations");
+    T3_REQUIRE(!a.c_tiled || epi == EPI_SILU, "gemm: only the SiLU form writes tile-ordered output");
     T3_REQUIRE(a.K == 1024 || a.K == 4096, "gemm: K must be 1024 or 4096");
     switch (epi) {
         case EPI_STORE:

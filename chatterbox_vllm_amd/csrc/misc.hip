@@ -69,7 +69,7 @@ template <int NSPLIT>
 __global__ __launch_bounds__(SLAB_NORM_THREADS) void slab_add_rmsnorm_kernel(const float* __restrict__ slab,
                                                                size_t slab_stride, bf16_t* __restrict__ res,
                                                                const bf16_t* __restrict__ w, bf16_t* __restrict__ xn,
-                                                               float eps) {
+                                                               float eps, int xn_tiled) {
     constexpr int d = 1024;
     constexpr int NT = SLAB_NORM_THREADS, EPT = d / NT, NV = EPT / 4;   // elements per thread, fp32x4 pieces per thread
     __shared__ float part[NT / 64];
@@ -126,7 +126,10 @@ __global__ __launch_bounds__(SLAB_NORM_THREADS) void slab_add_rmsnorm_kernel(con
         u32x4 o;
 #pragma unroll
         for (int i = 0; i < 4; ++i) o[i] = pack_bf2(rbf(z[2 * i] * sc) * wz[2 * i], rbf(z[2 * i + 1] * sc) * wz[2 * i + 1]);
-        *reinterpret_cast<u32x4*>(xn + row * d + c) = o;
+        // activation tile order (t3_common.h): this thread's 8 columns are one 16-byte fragment piece
+        const size_t off = xn_tiled ? ((row >> 4) * (d >> 5) + (tid >> 2)) * 512 + ((tid & 3) * 16 + (row & 15)) * 8
+                                    : row * d + c;
+        *reinterpret_cast<u32x4*>(xn + off) = o;
     } else {
         const u32x2 o = {pack_bf2(rbf(z[0] * sc) * wz[0], rbf(z[1] * sc) * wz[1]), pack_bf2(rbf(z[2] * sc) * wz[2], rbf(z[3] * sc) * wz[3])};
         *reinterpret_cast<u32x2*>(xn + row * d + c) = o;
@@ -134,13 +137,16 @@ __global__ __launch_bounds__(SLAB_NORM_THREADS) void slab_add_rmsnorm_kernel(con
 }
 
 int launch_slab_add_rmsnorm(const float* slab, int nsplit, bf16_t* res, const bf16_t* w, bf16_t* xn, int rows, int d,
-                            float eps, hipStream_t st) {
+                            float eps, hipStream_t st, bool xn_tiled) {
     T3_REQUIRE(rows >= 1 && d == 1024, "slab_add_rmsnorm: d must be 1024");
+    static_assert(SLAB_NORM_THREADS == 128, "the tile-ordered store assumes 8 columns per thread");
     T3_REQUIRE(nsplit == 0 || (slab != nullptr && nsplit == GEMM_SLAB_SPLIT), "slab_add_rmsnorm: nsplit must be 0 or the split count");
     if (nsplit == 0)
-        T3_LAUNCH(slab_add_rmsnorm_kernel<0>, dim3(rows), dim3(SLAB_NORM_THREADS), 0, st, slab, (size_t)rows * d, res, w, xn, eps);
+        T3_LAUNCH(slab_add_rmsnorm_kernel<0>, dim3(rows), dim3(SLAB_NORM_THREADS), 0, st, slab, (size_t)rows * d, res, w, xn, eps,
+                  (int)xn_tiled);
     else
-        T3_LAUNCH(slab_add_rmsnorm_kernel<GEMM_SLAB_SPLIT>, dim3(rows), dim3(SLAB_NORM_THREADS), 0, st, slab, (size_t)rows * d, res, w, xn, eps);
+        T3_LAUNCH(slab_add_rmsnorm_kernel<GEMM_SLAB_SPLIT>, dim3(rows), dim3(SLAB_NORM_THREADS), 0, st, slab, (size_t)rows * d, res, w, xn,
+                  eps, (int)xn_tiled);
     T3_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -75,6 +75,11 @@ enum GemmEpilogue { EPI_STORE = 0, EPI_RESID = 1, EPI_SILU = 2, EPI_QKV_ROPE = 3
 
 struct GemmArgs {
     const bf16_t* A; int lda;          // activations [M, K]
+    // Activation tile order (decode buffers): tile (row block of 16, k block of 32) = 1 KiB at ((r/16)*(K/32) + k/32)*512
+    // elements, inside it element ((k%32)/8*16 + r%16)*8 + k%8: one 16-byte load per lane is an MFMA operand and a wave
+    // reads 1 KiB of contiguous memory.  Rows are padded to a multiple of 16 (padding is never stored from).
+    bool a_tiled;                      // A is in activation tile order (lda unused)
+    bool c_tiled;                      // EPI_SILU: h is written in activation tile order
     const int32_t* a_rows;             // optional gather of A rows (nullptr = identity)
     const bf16_t* Wt;                  // weights in tile order (bf16 tiles, or int8 pair tiles when wscale is set)
     const float* wscale;               // int8 weights: one scale per output column, nullptr = bf16 weights
@@ -108,7 +113,7 @@ int launch_gemm_prompt(int epi, const GemmArgs& a, hipStream_t st);
 // res = bf16(bf16(sum_s slab[s]) + res) when slab != nullptr (nsplit slabs of [rows, d] fp32);
 // xn = rmsnorm(res) * w.  One pass, the row stays in registers.
 int launch_slab_add_rmsnorm(const float* slab, int nsplit, bf16_t* res, const bf16_t* w, bf16_t* xn, int rows, int d,
-                            float eps, hipStream_t st);
+                            float eps, hipStream_t st, bool xn_tiled = false);
 int launch_repack(const bf16_t* w, bf16_t* wt, int N, int K, hipStream_t st);
 // W[N,K] bf16 -> int8 pair tiles (offset binary) + scale[N] = absmax(row) / 127 (1 for an all-zero row)
 int launch_quantize(const bf16_t* w, uint8_t* wq, float* scale, int N, int K, hipStream_t st);

@@ -169,6 +169,9 @@ int t3_op_slab_split(void);
  * xn = rmsnorm(res) * w; d must be 1024.  The decode-path partner of t3_op_gemm_slab. */
 int t3_op_slab_add_rmsnorm(const float* slab_dev, int32_t nsplit, void* res_dev, const void* w_dev, void* xn_dev,
                            int32_t rows, int32_t d, float eps, void* stream);
+/* Same with xn written in activation tile order (t3_gemm_desc), what the decode step's projections read. */
+int t3_op_slab_add_rmsnorm_tiled(const float* slab_dev, int32_t nsplit, void* res_dev, const void* w_dev, void* xn_dev,
+                                 int32_t rows, int32_t d, float eps, void* stream);
 /* h[M,F] = bf16(bf16(silu(g)) * u) with [g|u] = bf16(A[M,K] @ Wgu[2F,K]^T)  (LlamaMLP). */
 int t3_op_gemm_silu(const void* a_dev, const void* wt_dev, void* h_dev, int32_t M, int32_t F, int32_t K,
                     void* stream);
@@ -208,6 +211,10 @@ typedef struct t3_gemm_desc {
     int32_t H, hd, layer, max_pages;                           /* epilogue 3, as t3_op_gemm_qkv_rope   */
     const void* rope_dev; const int32_t* pos_dev; const int32_t* stream_dev; void* kv_pool_dev;
     int64_t layer_stride_elems; const int32_t* block_table_dev;
+    /* Activation tile order, the layout of the decode step's intermediate buffers: rows padded to a multiple
+     * of 16; element (r, k) at ((r/16)*(K/32) + k/32)*512 + ((k%32)/8*16 + r%16)*8 + k%8.                    */
+    int32_t a_tiled;              /* a_dev is in activation tile order (streaming form only)                  */
+    int32_t out_tiled;            /* epilogue 2: h is written in activation tile order (streaming form only)  */
 } t3_gemm_desc;
 int t3_op_gemm_ex(const t3_gemm_desc* desc, void* stream);
 /* Single-query attention over the paged KV cache: row r attends to positions

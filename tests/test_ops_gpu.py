@@ -443,3 +443,67 @@ def test_int8_projections_match_dequantised_weights(capi, M, prompt):
         pg = int(bt[0, int(pos[r]) // 64])
         assert torch.equal(v[pg, 0, :, int(pos[r]) % 64, :].reshape(-1), qkv[r, 1024:2048].cpu())
         assert torch.equal(v[pg, 1, :, int(pos[r]) % 64, :].reshape(-1), qkv[r, 2048:].cpu())
+
+
+# ---- activation tile order (the decode step's intermediate layout) ---------------------------------------
+def _tile_act(a):
+    """[M, K] -> activation tile order: rows padded to 16; element (r, k) at
+    ((r//16)*(K//32) + k//32)*512 + ((k%32)//8*16 + r%16)*8 + k%8."""
+    M, K = a.shape
+    Mp = (M + 15) // 16 * 16
+    pad = torch.zeros(Mp, K, dtype=a.dtype, device=a.device)
+    pad[:M] = a
+    return pad.view(Mp // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous().view(-1)
+
+
+def _untile_act(t, M, K):
+    Mp = (M + 15) // 16 * 16
+    return t.view(Mp // 16, K // 32, 4, 16, 8).permute(0, 3, 1, 2, 4).reshape(Mp, K)[:M]
+
+
+@pytest.mark.parametrize("M", [1, 20, 52, 64, 100])
+def test_tile_ordered_activations_give_the_same_bits(capi, M):
+    """Every decode projection fed tile-ordered activations (and the SiLU form writing them) returns exactly the
+    bits of the row-major call: the layout changes addresses, not arithmetic."""
+    K, F = 1024, 4096
+    a = _rand((M, K), 90).to(DEV)
+    at = _tile_act(a)
+    w = _rand((2 * F, K), 91, 0.05).to(DEV)
+    wt = repack(capi, w)
+    Mp = (M + 15) // 16 * 16
+    # store (head-shaped) and SiLU
+    for epi, N_out in ((0, 2 * F), (2, F)):
+        outs = []
+        for tiled in (0, 1):
+            out = torch.full((Mp * N_out,), 3.0, dtype=torch.bfloat16, device=DEV)
+            d = _desc(a_dev=at if tiled else a, w_dev=wt, out_dev=out, M=M, N=2 * F, K=K, ldc=2 * F, epilogue=epi,
+                      a_tiled=tiled, out_tiled=tiled if epi == 2 else 0)
+            call(capi, "t3_op_gemm_ex", C.byref(d), None)
+            torch.cuda.synchronize()
+            outs.append(out)
+        plain = outs[0][: M * N_out].view(M, N_out)
+        got = _untile_act(outs[1], M, N_out) if epi == 2 else outs[1][: M * N_out].view(M, N_out)
+        assert torch.equal(got, plain), f"epilogue {epi}"
+    # split-K slabs over K = 4096 (down_proj reads the tile-ordered h) and the norm that writes tile order
+    h = _rand((M, F), 92).to(DEV)
+    wd = _rand((1024, F), 93, 0.02).to(DEV)
+    wdt = repack(capi, wd)
+    S = capi.t3_op_slab_split()
+    slabs = []
+    for tiled in (0, 1):
+        slab = torch.zeros(S, M, 1024, device=DEV)
+        hin = _tile_act(h) if tiled else h
+        d = _desc(a_dev=hin, w_dev=wdt, slab_dev=slab, M=M, N=1024, K=F, epilogue=4, a_tiled=tiled)
+        call(capi, "t3_op_gemm_ex", C.byref(d), None)
+        torch.cuda.synchronize()
+        slabs.append(slab)
+    assert torch.equal(slabs[0], slabs[1])
+    res = _rand((M, 1024), 94).to(DEV)
+    g = (1 + 0.1 * _rand((1024,), 95).float()).to(torch.bfloat16).to(DEV)
+    r1, r2 = res.clone(), res.clone()
+    xn1 = torch.zeros(M, 1024, dtype=torch.bfloat16, device=DEV)
+    xn2 = torch.zeros(Mp * 1024, dtype=torch.bfloat16, device=DEV)
+    call(capi, "t3_op_slab_add_rmsnorm", p(slabs[0]), S, p(r1), p(g), p(xn1), M, 1024, C.c_float(1e-5), None)
+    call(capi, "t3_op_slab_add_rmsnorm_tiled", p(slabs[0]), S, p(r2), p(g), p(xn2), M, 1024, C.c_float(1e-5), None)
+    torch.cuda.synchronize()
+    assert torch.equal(r1, r2) and torch.equal(_untile_act(xn2, M, 1024), xn1)

@@ -154,6 +154,8 @@ def main():
                     help="admission order of the queue: longest request first keeps the 32 slots full until the queue "
                          "is nearly dry (mean 31 of 32 slots busy against 26 with first come first served); "
                          "token ids are the same under both")
+    ap.add_argument("--uncond-no-attention", action="store_true",
+                    help="engine mode cfg_paired=2: the uncond row has no attention and no KV (not the benchmark)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="collective backend under torchrun; gloo (CPU tensors, ranks may share a GPU) rehearses the "
                          "multi-rank path on a box with fewer GPUs than ranks")
@@ -193,7 +195,7 @@ def main():
     eng = T3Engine(cfg, sd, max_model_len=MAX_MODEL_LEN, max_num_seqs=conc, cfg_scale=CFG_SCALE,
                    cfg_paired=paired, device=local_rank, max_prefill_rows=2048,
                    quantization=None if args.quantization == "none" else args.quantization,
-                   scheduling_policy=args.policy)
+                   scheduling_policy=args.policy, uncond_attends=not args.uncond_no_attention)
 
     def barrier():
         if dist is not None:
@@ -242,7 +244,7 @@ def main():
                                 "scale 3.0, greedy, max_model_len 1000; per GPU"}[args.workload],
                        "requests_per_gpu": len(job), "tokens_per_step_per_gpu": tokens // max(1, args.steps),
                        "concurrency": conc, "layers": cfg.n_layers, "weights": "int8 (W8A16)" if args.quantization == "int8" else "bf16",
-                       "admission": args.policy,
+                       "admission": args.policy, "uncond_stream": "no attention, no KV" if args.uncond_no_attention else "own KV",
                        "parallelism": f"request-sharded x{world}"},
             "per_gpu_tokens_per_s": round(total_tokens / dt / world, 2),
             "decode": {"steps": stats["decode_steps"],

@@ -99,7 +99,10 @@ struct Pinned {
 struct t3_engine {
     t3_config cfg{};
     hipStream_t stream = nullptr;
-    int nstreams_per_req = 1, n_streams = 0, max_pages = 0;
+    int rows_per_req = 1;                               // rows a request contributes to a step (2 with CFG pairing)
+    int kv_per_req = 1;                                 // KV streams a request owns (2 when the uncond stream attends)
+    bool uncond_ghost = false;                          // cfg_paired == 2: the uncond row gets no attention and no KV
+    int n_streams = 0, n_rows = 0, max_pages = 0;       // KV streams / decode rows of a full engine
     int head_n = 0;                                     // speech vocab padded to 16
     bool finalized = false;
 
@@ -363,12 +366,12 @@ int pages_for(int positions) { return (positions + T3_PAGE - 1) / T3_PAGE; }
 int grow_pages(t3_engine* e, Request& r, int positions) {
     const int need = pages_for(positions);
     while (r.have_pages < need) {
-        for (int u = 0; u < e->nstreams_per_req; ++u) {
+        for (int u = 0; u < e->kv_per_req; ++u) {
             if (e->free_pages.empty()) { t3_set_error("KV pool exhausted despite reservation"); return 1; }
             const int32_t pg = e->free_pages.back(); e->free_pages.pop_back();
-            e->block_table.h[(size_t)(r.slot * e->nstreams_per_req + u) * e->max_pages + r.have_pages] = pg;
+            e->block_table.h[(size_t)(r.slot * e->kv_per_req + u) * e->max_pages + r.have_pages] = pg;
         }
-        e->reserved_unallocated -= e->nstreams_per_req;
+        e->reserved_unallocated -= e->kv_per_req;
         r.have_pages++;
         e->block_table_dirty = true;
     }
@@ -376,10 +379,10 @@ int grow_pages(t3_engine* e, Request& r, int positions) {
 }
 
 void release_request(t3_engine* e, Request& r) {
-    for (int u = 0; u < e->nstreams_per_req; ++u)
+    for (int u = 0; u < e->kv_per_req; ++u)
         for (int p = 0; p < r.have_pages; ++p)
-            e->free_pages.push_back(e->block_table.h[(size_t)(r.slot * e->nstreams_per_req + u) * e->max_pages + p]);
-    e->reserved_unallocated -= (int64_t)(r.reserve_pages - r.have_pages) * e->nstreams_per_req;
+            e->free_pages.push_back(e->block_table.h[(size_t)(r.slot * e->kv_per_req + u) * e->max_pages + p]);
+    e->reserved_unallocated -= (int64_t)(r.reserve_pages - r.have_pages) * e->kv_per_req;
 }
 
 // The host table keeps changing while earlier copies may still be queued, so each step uploads
@@ -398,7 +401,7 @@ int sync_block_table(t3_engine* e) {
 int run_prefill(t3_engine* e, const std::vector<Request*>& reqs) {
     const t3_config& c = e->cfg;
     t3_engine::Meta& m = e->pm[e->parity];
-    const int S = e->nstreams_per_req, n = (int)reqs.size();
+    const int S = e->rows_per_req, Q = e->kv_per_req, n = (int)reqs.size();
     int row = 0, nseq = 0, ntiles = 0, pid = 0;
     for (int i = 0; i < n; ++i) {
         Request& r = *reqs[i];
@@ -406,11 +409,11 @@ int run_prefill(t3_engine* e, const std::vector<Request*>& reqs) {
         if (grow_pages(e, r, P)) return 1;
         T3_HIP_CHECK(hipMemcpyAsync(e->cond_buf + (size_t)r.slot * kCondRows * c.d_model, r.cond.data(),
                                     sizeof(float) * kCondRows * c.d_model, hipMemcpyHostToDevice, e->stream));
-        for (int u = 0; u < S; ++u) {
+        for (int u = 0; u < Q; ++u) {
             m.seq_start[nseq] = row;
             for (int q0 = 0; q0 < P; q0 += 64) { m.tiles[2 * ntiles] = nseq; m.tiles[2 * ntiles + 1] = q0; ++ntiles; }
             for (int p = 0; p < P; ++p, ++row) {
-                m.row_stream[row] = r.slot * S + u;
+                m.row_stream[row] = r.slot * Q + u;
                 m.row_pos[row] = p;
                 m.row_ctx[row] = p + 1;
                 if (p < kCondRows) { m.ekind[row] = 0; m.eidx[row] = p; m.eaux[row] = r.slot; }
@@ -435,6 +438,15 @@ int run_prefill(t3_engine* e, const std::vector<Request*>& reqs) {
         (void)base;
     }
     m.seq_start[nseq] = row;
+    // An uncond stream without attention has no history: only its last prompt row (the start-of-speech row) reaches the
+    // sampler.  Those rows follow the real sequences, belong to no attention tile and keep an all-zero attention input.
+    const int first_ghost = row;
+    if (e->uncond_ghost)
+        for (int i = 0; i < n; ++i, ++row) {
+            m.row_stream[row] = -1; m.row_pos[row] = reqs[i]->prompt_len - 1; m.row_ctx[row] = 0;
+            m.ekind[row] = 3; m.eidx[row] = 0; m.eaux[row] = 0;
+            m.a_rows[n + i] = row;
+        }
     const int rows = row;
     e->kphase = 1;
     if (sync_block_table(e)) return 1;
@@ -454,6 +466,9 @@ int run_prefill(t3_engine* e, const std::vector<Request*>& reqs) {
     ea.cond = e->cond_buf; ea.text_emb = e->text_emb; ea.text_pos = e->text_pos;
     ea.speech_emb = e->speech_emb; ea.speech_pos = e->speech_pos; ea.last_token = e->last_token; ea.sos_id = kSOS;
     T3_RUN(e, K_EMBED, -1, 2LL * rows * c.d_model, launch_embed(ea, e->stream));
+    if (rows > first_ghost)
+        T3_HIP_CHECK(hipMemsetAsync(e->b->att + (size_t)first_ghost * c.d_model, 0,
+                                    sizeof(bf16_t) * (size_t)(rows - first_ghost) * c.d_model, e->stream));
     if (run_layers(e, rows, dev_of(m.i32, m.row_pos), dev_of(m.i32, m.row_stream), dev_of(m.i32, m.row_ctx), true,
                    dev_of(m.i32, m.seq_start), dev_of(m.i32, m.tiles), ntiles)) return 1;
     if (run_head_and_sample(e, m, n * S, dev_of(m.i32, m.a_rows), n)) return 1;
@@ -465,7 +480,7 @@ int run_prefill(t3_engine* e, const std::vector<Request*>& reqs) {
 // ---- one decode token for the running requests -------------------------------------------
 int enqueue_decode(t3_engine* e, t3_engine::Meta& m, int B) {
     const t3_config& c = e->cfg;
-    const int rows = B * e->nstreams_per_req;
+    const int rows = B * e->rows_per_req;
     EmbedArgs ea{};
     ea.out = e->b->res; ea.d = c.d_model; ea.rows = rows;
     ea.kind = dev_of(m.i32, m.ekind); ea.idx = dev_of(m.i32, m.eidx); ea.aux = dev_of(m.i32, m.eaux);
@@ -478,7 +493,7 @@ int enqueue_decode(t3_engine* e, t3_engine::Meta& m, int B) {
 }
 
 int run_decode(t3_engine* e, const std::vector<Request*>& reqs) {
-    const int S = e->nstreams_per_req, B = (int)reqs.size();
+    const int S = e->rows_per_req, Q = e->kv_per_req, B = (int)reqs.size();
     t3_engine::Meta& m = e->dm[e->parity];
     int64_t ctx_total = 0;
     for (int i = 0; i < B; ++i) {
@@ -487,11 +502,12 @@ int run_decode(t3_engine* e, const std::vector<Request*>& reqs) {
         if (grow_pages(e, r, pos + 1)) return 1;
         for (int u = 0; u < S; ++u) {
             const int row = i * S + u;
-            m.row_stream[row] = r.slot * S + u;
+            const bool ghost = u >= Q;                        // uncond row without attention: no stream, no context
+            m.row_stream[row] = ghost ? -1 : r.slot * Q + u;
             m.row_pos[row] = pos;
-            m.row_ctx[row] = pos + 1;
+            m.row_ctx[row] = ghost ? 0 : pos + 1;
             m.ekind[row] = 4; m.eidx[row] = r.slot; m.eaux[row] = 0;
-            ctx_total += pos + 1;
+            if (!ghost) ctx_total += pos + 1;
         }
         m.row_c[i] = i * S;
         m.row_u[i] = S == 2 ? i * S + 1 : -1;
@@ -554,8 +570,12 @@ extern "C" int t3_engine_create(const t3_config* cfg, t3_engine** out) {
     e->cfg = *cfg;
     if (e->cfg.max_prefill_rows < e->cfg.max_model_len) e->cfg.max_prefill_rows = e->cfg.max_model_len;
     const t3_config& c = e->cfg;
-    e->nstreams_per_req = c.cfg_paired ? 2 : 1;
-    e->n_streams = c.max_num_seqs * e->nstreams_per_req;
+    T3_REQUIRE(c.cfg_paired >= 0 && c.cfg_paired <= 2, "cfg_paired must be 0, 1 or 2");
+    e->rows_per_req = c.cfg_paired ? 2 : 1;
+    e->uncond_ghost = c.cfg_paired == 2;
+    e->kv_per_req = c.cfg_paired == 1 ? 2 : 1;
+    e->n_streams = c.max_num_seqs * e->kv_per_req;
+    e->n_rows = c.max_num_seqs * e->rows_per_req;
     e->max_pages = pages_for(c.max_model_len);
     e->head_n = (c.speech_vocab + 15) / 16 * 16;
     T3_HIP_CHECK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
@@ -566,7 +586,7 @@ extern "C" int t3_engine_create(const t3_config* cfg, t3_engine** out) {
 
     // KV pool
     e->n_pages = c.kv_pages > 0 ? c.kv_pages : (int64_t)e->n_streams * e->max_pages;
-    T3_REQUIRE(e->n_pages >= (int64_t)e->nstreams_per_req * e->max_pages, "kv_pages cannot hold one full request");
+    T3_REQUIRE(e->n_pages >= (int64_t)e->kv_per_req * e->max_pages, "kv_pages cannot hold one full request");
     const int64_t page_elems = 2LL * c.n_heads * T3_PAGE * c.head_dim;
     e->layer_stride = e->n_pages * page_elems;
     const size_t pool_elems = (size_t)e->layer_stride * c.n_layers;
@@ -577,10 +597,10 @@ extern "C" int t3_engine_create(const t3_config* cfg, t3_engine** out) {
     if (e->block_table.alloc((size_t)e->n_streams * e->max_pages)) return 1;
 
     // activations
-    const int prefill_rows = c.max_prefill_rows * e->nstreams_per_req;
-    e->max_rows = (std::max(prefill_rows, e->n_streams) + 127) / 128 * 128;   // whole row tiles for the tile-ordered buffers
+    const int prefill_rows = c.max_prefill_rows * e->kv_per_req + (e->uncond_ghost ? c.max_num_seqs : 0);
+    e->max_rows = (std::max(prefill_rows, e->n_rows) + 127) / 128 * 128;   // whole row tiles for the tile-ordered buffers
     {
-        const size_t R = (size_t)e->max_rows, RD = (size_t)e->n_streams;
+        const size_t R = (size_t)e->max_rows, RD = (size_t)e->n_rows;
         t3_engine::Bufs& b = e->bufs;
         if (dmalloc(&b.res, R * c.d_model) || dmalloc(&b.xn, R * c.d_model) || dmalloc(&b.qkv, R * 3 * c.d_model) ||
             dmalloc(&b.att, R * c.d_model) || dmalloc(&b.hbuf, R * c.d_ff) || dmalloc(&b.logits, RD * e->head_n)) return 1;
@@ -601,7 +621,7 @@ extern "C" int t3_engine_create(const t3_config* cfg, t3_engine** out) {
     T3_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->dbg_logits),
                            sizeof(float) * c.max_num_seqs * (size_t)(c.speech_vocab + kOffset)));
     for (int q = 0; q < 2; ++q) {
-        if (meta_alloc(e->dm[q], e->n_streams, c.max_num_seqs, 16)) return 1;
+        if (meta_alloc(e->dm[q], e->n_rows, c.max_num_seqs, 16)) return 1;
         if (meta_alloc(e->pm[q], prefill_rows, c.max_num_seqs, (size_t)c.max_prefill_rows + (size_t)c.max_num_seqs * 64)) return 1;
     }
     for (auto& ev : e->ev) T3_HIP_CHECK(hipEventCreate(&ev));
@@ -924,7 +944,7 @@ extern "C" int t3_engine_step(t3_engine* e, int64_t* out_req_ids, int32_t* out_t
         int slot = -1;
         for (int i = 0; i < c.max_num_seqs; ++i) if (!e->slots[i]) { slot = i; break; }
         if (slot < 0) break;
-        const int64_t need = (int64_t)r.reserve_pages * e->nstreams_per_req;
+        const int64_t need = (int64_t)r.reserve_pages * e->kv_per_req;
         if ((int64_t)e->free_pages.size() - e->reserved_unallocated < need) break;
         if (r.prompt_len > row_budget) break;
         row_budget -= r.prompt_len;

@@ -78,7 +78,7 @@ class T3Engine:
                  max_model_len: int = 1000, max_num_seqs: int = 32, cfg_scale: Optional[float] = None,
                  cfg_paired: Optional[bool] = None, device: int = 0, enforce_eager: bool = False,
                  kv_pages: int = 0, max_prefill_rows: int = 2048, quantization: Optional[str] = None,
-                 scheduling_policy: str = "fcfs", **_ignored_vllm_kwargs):
+                 scheduling_policy: str = "fcfs", uncond_attends: bool = True, **_ignored_vllm_kwargs):
         if cfg_scale is None:                      # models/t3/t3.py:343
             cfg_scale = float(os.environ.get("CHATTERBOX_CFG_SCALE", "0.5"))
         if cfg_paired is None:
@@ -89,6 +89,9 @@ class T3Engine:
         self.max_num_seqs = int(max_num_seqs)
         self.cfg_scale = float(cfg_scale)
         self.cfg_paired = bool(cfg_paired)
+        # uncond_attends=False: the uncond half is a context-free row (zero attention output at every layer, no KV),
+        # the arithmetic a serving stack performs when it attends only the rows its scheduler counted
+        self.uncond_attends = bool(uncond_attends)
         self.device = int(device)
         if quantization not in (None, "int8"):
             raise ValueError(f"unsupported quantization {quantization!r}: None or 'int8' (W8A16, per output channel)")
@@ -99,7 +102,7 @@ class T3Engine:
             n_layers=m.n_layers, d_model=m.d_model, n_heads=m.n_heads, head_dim=m.head_dim, d_ff=m.d_ff,
             text_vocab=m.text_vocab, speech_vocab=m.speech_vocab, text_pos_rows=m.text_pos_rows,
             speech_pos_rows=m.speech_pos_rows, max_model_len=self.max_model_len, max_num_seqs=self.max_num_seqs,
-            cfg_paired=int(self.cfg_paired), max_prefill_rows=int(max_prefill_rows), device=self.device,
+            cfg_paired=(1 if self.uncond_attends else 2) if self.cfg_paired else 0, max_prefill_rows=int(max_prefill_rows), device=self.device,
             use_graphs=int(not enforce_eager), weight_int8=int(quantization == "int8"), cfg_scale=self.cfg_scale, rms_eps=m.rms_eps,
             kv_pages=int(kv_pages))
         self._h = C.c_void_p()

@@ -35,7 +35,11 @@ typedef struct t3_config {
     int32_t text_vocab, speech_vocab, text_pos_rows, speech_pos_rows;
     int32_t max_model_len;     /* prompt + generated positions per request            */
     int32_t max_num_seqs;      /* requests decoded concurrently                       */
-    int32_t cfg_paired;        /* 1: each request runs a cond and an uncond KV stream */
+    int32_t cfg_paired;        /* 0: one stream per request, no CFG.  1: a cond and an uncond stream, each with its
+                                  own KV (what models/t3/t3.py:742-778 and the reference's README describe).
+                                  2: cond + uncond rows, but the uncond row gets NO attention output and no KV: what
+                                  the reference computes if the serving stack attends only the rows its scheduler
+                                  counted (the model doubles the rows behind the scheduler's back, t3.py:762-770) */
     int32_t max_prefill_rows;  /* prompt rows (per stream) admitted in one step       */
     int32_t device;            /* HIP device ordinal                                  */
     int32_t use_graphs;        /* 1: replay decode steps from captured HIP graphs     */

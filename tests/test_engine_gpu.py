@@ -368,3 +368,29 @@ def test_full_size_job_rows_do_not_depend_on_the_batch():
     for i in (5, lens.index(min(lens)), 17):
         alone, _ = run([i], 1, "fcfs", eager=True)
         assert alone[0] == full[i], f"request {i} differs between the loaded engine and a run alone"
+
+
+def test_uncond_without_attention_mode_matches_its_oracle(small):
+    """cfg_paired = 2 (uncond_attends=False): the uncond row has no history (zero attention output, no KV).  Same bar
+    against the oracle in its ``uncond_attends=False`` mode; results differ from the default mode, do not depend on
+    the batch, and only the cond stream takes KV pages."""
+    cfg, sd = small
+    texts = [_text(n, 700 + n) for n in (2, 15, 44, 80)]
+    voices = [0, 1, 2, 1]
+    sp = SamplingParams(temperature=0.0, repetition_penalty=2.0, max_tokens=25, stop_token_ids=[STOP])
+    eng = T3Engine(cfg, sd, max_model_len=200, max_num_seqs=4, cfg_scale=3.0, uncond_attends=False, kv_pages=4 * 4)
+    ids, logits, _ = _run_with_logits(eng, _items(texts, voices), sp)
+    plain = eng.generate(_items(texts, voices), sp)
+    assert [o.outputs[0].token_ids for o in plain] == ids
+    assert eng.stats().free_pages == 16
+    eng.shutdown()
+    oracle = T3Oracle(sd, n_layers=cfg.n_layers, cfg_scale=3.0, uncond_attends=False)
+    for t, v, i, l in zip(texts, voices, ids, logits):
+        _check_against_oracle(oracle, i, l, t, W.synthetic_cond_emb(v), SamplingSpec(max_tokens=25), 200, True, 3.0)
+    one = T3Engine(cfg, sd, max_model_len=200, max_num_seqs=1, cfg_scale=3.0, uncond_attends=False, enforce_eager=True)
+    assert one.generate(_items(texts[2:3], voices[2:3]), sp)[0].outputs[0].token_ids == ids[2]
+    one.shutdown()
+    full = T3Engine(cfg, sd, max_model_len=200, max_num_seqs=4, cfg_scale=3.0)
+    other = [o.outputs[0].token_ids for o in full.generate(_items(texts, voices), sp)]
+    full.shutdown()
+    assert other != ids

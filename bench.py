@@ -156,6 +156,8 @@ def main():
                          "token ids are the same under both")
     ap.add_argument("--uncond-no-attention", action="store_true",
                     help="engine mode cfg_paired=2: the uncond row has no attention and no KV (not the benchmark)")
+    ap.add_argument("--no-prefix-sharing", action="store_true",
+                    help="every stream prefills and keeps its own copy of the 34 conditioning positions (same ids)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="collective backend under torchrun; gloo (CPU tensors, ranks may share a GPU) rehearses the "
                          "multi-rank path on a box with fewer GPUs than ranks")
@@ -195,7 +197,8 @@ def main():
     eng = T3Engine(cfg, sd, max_model_len=MAX_MODEL_LEN, max_num_seqs=conc, cfg_scale=CFG_SCALE,
                    cfg_paired=paired, device=local_rank, max_prefill_rows=2048,
                    quantization=None if args.quantization == "none" else args.quantization,
-                   scheduling_policy=args.policy, uncond_attends=not args.uncond_no_attention)
+                   scheduling_policy=args.policy, uncond_attends=not args.uncond_no_attention,
+                   prefix_sharing=not args.no_prefix_sharing)
 
     def barrier():
         if dist is not None:
@@ -245,6 +248,7 @@ def main():
                        "requests_per_gpu": len(job), "tokens_per_step_per_gpu": tokens // max(1, args.steps),
                        "concurrency": conc, "layers": cfg.n_layers, "weights": "int8 (W8A16)" if args.quantization == "int8" else "bf16",
                        "admission": args.policy, "uncond_stream": "no attention, no KV" if args.uncond_no_attention else "own KV",
+                       "cond_prefix_kv": "per stream" if args.no_prefix_sharing else "shared per voice",
                        "parallelism": f"request-sharded x{world}"},
             "per_gpu_tokens_per_s": round(total_tokens / dt / world, 2),
             "decode": {"steps": stats["decode_steps"],

@@ -11,7 +11,7 @@ import os
 from functools import lru_cache
 
 LIB_NAME = "libt3hip.so"
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class T3Error(RuntimeError):
@@ -26,6 +26,7 @@ class T3Config(C.Structure):
         ("max_num_seqs", C.c_int32), ("cfg_paired", C.c_int32), ("max_prefill_rows", C.c_int32),
         ("device", C.c_int32), ("use_graphs", C.c_int32), ("weight_int8", C.c_int32),
         ("cfg_scale", C.c_float), ("rms_eps", C.c_float), ("kv_pages", C.c_int64),
+        ("prefix_sharing", C.c_int32), ("max_voices", C.c_int32),
     ]
 
 

@@ -23,10 +23,17 @@
 // the 8 groups of a wave by butterflies and across waves through LDS in wave order.  The
 // tile -> wave -> merge order depends only on the row's own context length, never on the
 // batch, so results are bit-identical for any batch composition.
+//
+// Shared prefix: when row_pfx[r] >= 0, positions [0, npfx) of row r live in page row_pfx[r]
+// (one copy for every stream that starts with the same conditioning rows) and the row's own
+// page 0 holds only positions [npfx, 64).  The tile boundaries stay where they are, each lane
+// just picks the page its token is in, so the result has the same bits as with private
+// copies, and all rows of a step read the same few KiB, which then come from L2.
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(ATT_NW * 64) void attn_decode_kernel(
         const bf16_t* __restrict__ qkv, int ldq, bf16_t* __restrict__ out, int ldo,
-        const int32_t* __restrict__ row_stream, const int32_t* __restrict__ row_ctx, KvView kv, int layer
+        const int32_t* __restrict__ row_stream, const int32_t* __restrict__ row_ctx, KvView kv, int layer,
+        const int32_t* __restrict__ row_pfx, int npfx
 #ifdef T3_ATTN_TIMELINE
         , long long* ts
 #endif
@@ -44,6 +51,7 @@ __global__ __launch_bounds__(ATT_NW * 64) void attn_decode_kernel(
     const int c = lane & 7, tg = lane >> 3;
     const int st = row_stream[r];
     const int ctx = row_ctx[r];
+    const int pfx = row_pfx ? row_pfx[r] : -1;
     const int hd = 64;
 
     float q[8];
@@ -62,13 +70,24 @@ __global__ __launch_bounds__(ATT_NW * 64) void attn_decode_kernel(
     for (int tile = w; tile < ntiles; tile += ATT_NW) {
         const int page = kv.block_table[(size_t)st * kv.max_pages + tile];
         const bf16_t* kb = lbase + ((size_t)page * 2 * kv.H + h) * slab + lane * 8;
-        const bf16_t* vb = kb + (size_t)kv.H * slab;
+        // lanes whose token lies in the shared prefix read the prefix page (tile 0 only): an element
+        // offset between the two pages, zero everywhere else
+        const bool shared = tile == 0 && pfx >= 0;
+        const long long to_pfx = shared ? ((long long)pfx - page) * (long long)(2 * kv.H) * (long long)slab : 0;
+        const int lim = shared ? npfx : 0;
+        const size_t vofs = (size_t)kv.H * slab;
         u32x4 kr[8], vr[8];
         if (tile == w) ATT_STAMP(1);
 #pragma unroll
-        for (int it = 0; it < 8; ++it) kr[it] = ATT_LOAD(reinterpret_cast<const u32x4*>(kb + it * 512));
+        for (int it = 0; it < 8; ++it) {
+            const bf16_t* p = kb + it * 512 + (it * 8 + tg < lim ? to_pfx : 0);
+            kr[it] = ATT_LOAD(reinterpret_cast<const u32x4*>(p));
+        }
 #pragma unroll
-        for (int it = 0; it < 8; ++it) vr[it] = ATT_LOAD(reinterpret_cast<const u32x4*>(vb + it * 512));
+        for (int it = 0; it < 8; ++it) {
+            const bf16_t* p = kb + vofs + it * 512 + (it * 8 + tg < lim ? to_pfx : 0);
+            vr[it] = ATT_LOAD(reinterpret_cast<const u32x4*>(p));
+        }
         float s[8];
         float mt = m;
 #pragma unroll
@@ -147,11 +166,13 @@ __global__ __launch_bounds__(ATT_NW * 64) void attn_decode_kernel(
 
 #ifndef T3_ATTN_TIMELINE
 int launch_attn_decode(const bf16_t* qkv, int ldq, bf16_t* out, int rows, const int32_t* row_stream,
-                       const int32_t* row_ctx, const KvView& kv, int layer, hipStream_t st) {
+                       const int32_t* row_ctx, const KvView& kv, int layer, hipStream_t st,
+                       const int32_t* row_pfx, int npfx) {
     T3_REQUIRE(kv.hd == 64, "attn_decode: head_dim must be 64");
     T3_REQUIRE(rows >= 1 && ldq % 8 == 0, "attn_decode: bad shape");
+    T3_REQUIRE(row_pfx == nullptr || (npfx >= 1 && npfx <= T3_PAGE), "attn_decode: the shared prefix must fit one page");
     T3_LAUNCH(attn_decode_kernel, dim3(kv.H, rows), dim3(ATT_NW * 64), 0, st, qkv, ldq, out,
-                       kv.H * kv.hd, row_stream, row_ctx, kv, layer);
+                       kv.H * kv.hd, row_stream, row_ctx, kv, layer, row_pfx, npfx);
     T3_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -171,19 +192,32 @@ int launch_attn_decode(const bf16_t* qkv, int ldq, bf16_t* out, int rows, const 
 //                             is applied to the V^T fragment), no LDS round trip for P.
 // P is fed as hi + lo bf16 parts (two MFMAs), so the weights keep ~16 significant bits and the
 // result matches an fp32-softmax checker to bf16 rounding.  fp32 online softmax across key tiles.
+//
+// Shared prefix: a sequence with seq_pfx[seq] >= 0 brings rows for positions npfx.. only; keys
+// [0, npfx) are read from page seq_pfx[seq] of the KV pool (written by an earlier step, or by
+// the QKV projection of this very step when the prefix rows ride along as a sequence of their
+// own).  Key tiles stay aligned to absolute positions, and a query's result does not depend on
+// which queries share its tile, so the bits equal those of a prompt that carries its own prefix.
 // ------------------------------------------------------------------------------------
 #define PF_LD 72   // LDS row stride in elements (64 + 8 pad: 144 B keeps 16-B alignment, spreads banks)
 
 __global__ __launch_bounds__(256) void attn_prefill_kernel(const bf16_t* __restrict__ qkv, int ldq,
                                                            bf16_t* __restrict__ out, int ldo,
                                                            const int32_t* __restrict__ seq_start,
-                                                           const int32_t* __restrict__ tiles, int H) {
+                                                           const int32_t* __restrict__ tiles, int H,
+                                                           const int32_t* __restrict__ seq_pfx, int npfx,
+                                                           const bf16_t* __restrict__ pool_layer) {
     __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * PF_LD];
     __shared__ __attribute__((aligned(16))) bf16_t Vt[64 * PF_LD];
     const int hd = 64, D = H * hd;
-    const int seq = tiles[2 * blockIdx.x], q0 = tiles[2 * blockIdx.x + 1];
+    const int seq = tiles[2 * blockIdx.x];
     const int h = blockIdx.y;
-    const int s0 = seq_start[seq], P = seq_start[seq + 1] - s0;
+    // positions: the sequence's rows are positions base .. P-1; q0, qrow, key indices are positions
+    const int pfx = seq_pfx ? seq_pfx[seq] : -1;
+    const int base = pfx >= 0 ? npfx : 0;
+    const int s0 = seq_start[seq] - base, P = seq_start[seq + 1] - s0;     // row of position p = s0 + p
+    const int q0 = base + tiles[2 * blockIdx.x + 1];
+    const bf16_t* pk = pool_layer + ((size_t)(pfx >= 0 ? pfx : 0) * 2 * H + h) * (T3_PAGE * 64);   // prefix K slab of this head
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, c = lane & 15;
@@ -211,9 +245,10 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const bf16_t* __restr
             const int idx = tid + 256 * i, key = idx >> 3, ch = idx & 7;
             int gk = kt * 64 + key;
             gk = gk < P ? gk : P - 1;
-            const bf16_t* kp = qkv + (size_t)(s0 + gk) * ldq + D + h * hd + ch * 8;
+            const bool in_pfx = gk < base;
+            const bf16_t* kp = in_pfx ? pk + gk * 64 + ch * 8 : qkv + (size_t)(s0 + gk) * ldq + D + h * hd + ch * 8;
             const u32x4 kv = *reinterpret_cast<const u32x4*>(kp);
-            const u32x4 vv = *reinterpret_cast<const u32x4*>(kp + D);
+            const u32x4 vv = *reinterpret_cast<const u32x4*>(kp + (in_pfx ? (size_t)H * (T3_PAGE * 64) : (size_t)D));
             *reinterpret_cast<u32x4*>(&Ks[key * PF_LD + ch * 8]) = kv;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -296,10 +331,14 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const bf16_t* __restr
 }
 
 int launch_attn_prefill(const bf16_t* qkv, int ldq, bf16_t* out, const int32_t* seq_start_dev,
-                        const int32_t* tiles_dev, int ntiles, int H, int hd, hipStream_t st) {
+                        const int32_t* tiles_dev, int ntiles, int H, int hd, hipStream_t st,
+                        const int32_t* seq_pfx_dev, int npfx, const KvView* kv, int layer) {
     T3_REQUIRE(hd == 64 && ntiles >= 1, "attn_prefill: head_dim must be 64");
+    T3_REQUIRE(seq_pfx_dev == nullptr || (kv && kv->H == H && kv->hd == hd && npfx >= 1 && npfx <= T3_PAGE),
+               "attn_prefill: a shared prefix needs the KV pool and must fit one page");
+    const bf16_t* pool_layer = seq_pfx_dev ? kv->pool + (size_t)layer * kv->layer_stride : nullptr;
     T3_LAUNCH(attn_prefill_kernel, dim3(ntiles, H), dim3(256), 0, st, qkv, ldq, out, H * hd, seq_start_dev,
-                       tiles_dev, H);
+                       tiles_dev, H, seq_pfx_dev, npfx, pool_layer);
     T3_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -23,6 +23,17 @@
 // by step parity.  The measuring/debugging modes (timing, kernel timing, logit taps,
 // T3_DEBUG_SYNC, T3_ASYNC=0) run each step to completion inside the call instead.
 //
+// Shared conditioning prefix (cfg.prefix_sharing).  Positions 0..33 of every stream are the 34
+// conditioning rows: identical in the cond and the uncond stream of a request and in every
+// request that speaks with the same voice, so their K/V are identical too (the layers are
+// causal).  The engine keeps them once per voice in a page of its own: the first request that
+// brings a voice carries the 34 rows through the layers as a sequence of their own, inside the
+// same prefill launch; every stream of that voice then prefills only positions 34.. and reads
+// keys 0..33 from the voice page, in prefill and in decode.  Tile boundaries and summation
+// orders are those of private copies, so ids and logits are bit-identical to an engine without
+// sharing; what changes is 34 fewer prompt rows per stream and 34 fewer positions of KV to
+// fetch from HBM per row and layer (all rows read the same page, which stays in L2).
+//
 // KV pages hold 64 positions of one stream for all layers.  Pages are handed out lazily as a
 // stream grows; admission reserves the worst case (prompt + max_tokens, capped by
 // max_model_len) so a running request can never starve, and nothing is ever preempted.
@@ -67,7 +78,29 @@ struct Request {
     int reserve_pages = 0;            // worst-case pages per stream
     int have_pages = 0;               // pages allocated per stream
     bool aborted = false;
+    int voice = -1;                   // shared-prefix entry this request reads positions 0..33 from
+    bool builds_voice = false;        // its prefill step also carries the voice's 34 rows
 };
+
+// A conditioning prefix whose K/V live in a page of their own (prefix sharing).
+struct Voice {
+    std::vector<float> cond;          // [34, d] as given by the first request that brought it
+    uint64_t hash = 0;
+    int refs = 0;                     // requests between admission and release
+    uint64_t last_use = 0;
+    bool used = false;
+};
+
+uint64_t hash_floats(const float* p, size_t n) {
+    uint64_t h = 0x9E3779B97F4A7C15ULL;
+    for (size_t i = 0; i < n; ++i) {
+        uint32_t w;
+        std::memcpy(&w, p + i, 4);
+        h = (h ^ w) * 0x100000001B3ULL;
+        h ^= h >> 29;
+    }
+    return h;
+}
 
 struct Layer {
     bf16_t *ln1 = nullptr, *ln2 = nullptr, *wqkv = nullptr, *wo = nullptr, *wgu = nullptr, *wd = nullptr;
@@ -130,8 +163,15 @@ struct t3_engine {
     } bufs;
     Bufs* b = &bufs;
     int max_rows = 0;
-    int64_t cur_ctx_tokens = 0;                         // sum of context lengths of the decode rows being enqueued
-    float* cond_buf = nullptr;                          // [max_num_seqs][34][d] fp32
+    int64_t cur_ctx_tokens = 0;                         // positions of K/V the decode rows being enqueued must fetch: sum of
+                                                        // their context lengths, a shared prefix counted once per voice
+    float* cond_buf = nullptr;                          // [max_num_seqs or n_voices][34][d] fp32
+
+    // shared conditioning prefixes: voice v owns KV stream n_streams + v, whose only page is n_pages + v
+    bool share_prefix = false;
+    int n_voices = 0;
+    std::vector<Voice> voices;
+    uint64_t voice_clock = 0;
     uint8_t* seen = nullptr;                            // [max_num_seqs][kSeenStride]
     int32_t* last_token = nullptr;                      // [max_num_seqs]
     float* dbg_logits = nullptr;                        // [max_num_seqs][vocab+1000] when enabled
@@ -140,8 +180,8 @@ struct t3_engine {
     // per-step metadata: one pinned block, one H2D copy per phase
     struct Meta {
         Pinned<int32_t> i32; Pinned<float> f32; Pinned<uint64_t> u64;
-        int32_t *row_stream, *row_pos, *row_ctx, *ekind, *eidx, *eaux, *row_c, *row_u, *slot, *step, *a_rows,
-                *seq_start, *tiles, *prompt_ids, *out_tokens;     // host views
+        int32_t *row_stream, *row_pos, *row_ctx, *row_pfx, *ekind, *eidx, *eaux, *row_c, *row_u, *slot, *step, *a_rows,
+                *seq_start, *seq_pfx, *tiles, *prompt_ids, *out_tokens;     // host views
         float *rep, *temp, *top_p, *min_p;
         uint64_t* seed;
         size_t rows_cap = 0, req_cap = 0;
@@ -207,17 +247,18 @@ int ktime_end(t3_engine* e);
 
 int meta_alloc(t3_engine::Meta& m, size_t rows, size_t reqs, size_t prompt_ids) {
     m.rows_cap = rows; m.req_cap = reqs;
-    const size_t tiles = rows / 32 + 4 * reqs + 64;
-    const size_t ni = rows * 6 + reqs * 5 + reqs * 2 /*a_rows*/ + (2 * reqs + 2) + 2 * tiles + prompt_ids + 64;
+    // sequences of a prefill step: up to two streams per request plus one per voice built in the step
+    const size_t seqs = 3 * reqs + 2, tiles = rows / 32 + 5 * reqs + 64;
+    const size_t ni = rows * 7 + reqs * 5 + reqs * 2 /*a_rows*/ + 2 * seqs + 2 * tiles + prompt_ids + 64;
     if (m.i32.alloc(ni)) return 1;
     if (m.f32.alloc(reqs * 4 + 16)) return 1;
     if (m.u64.alloc(reqs + 4)) return 1;
     int32_t* p = m.i32.h;
-    m.row_stream = carve(p, rows); m.row_pos = carve(p, rows); m.row_ctx = carve(p, rows);
+    m.row_stream = carve(p, rows); m.row_pos = carve(p, rows); m.row_ctx = carve(p, rows); m.row_pfx = carve(p, rows);
     m.ekind = carve(p, rows); m.eidx = carve(p, rows); m.eaux = carve(p, rows);
     m.row_c = carve(p, reqs); m.row_u = carve(p, reqs); m.slot = carve(p, reqs); m.step = carve(p, reqs);
     m.out_tokens = carve(p, reqs);
-    m.a_rows = carve(p, 2 * reqs); m.seq_start = carve(p, 2 * reqs + 2); m.tiles = carve(p, 2 * tiles);
+    m.a_rows = carve(p, 2 * reqs); m.seq_start = carve(p, seqs); m.seq_pfx = carve(p, seqs); m.tiles = carve(p, 2 * tiles);
     m.prompt_ids = carve(p, prompt_ids);
     float* f = m.f32.h;
     m.rep = carve(f, reqs); m.temp = carve(f, reqs); m.top_p = carve(f, reqs); m.min_p = carve(f, reqs);
@@ -285,8 +326,9 @@ int ktime_collect(t3_engine* e) {
 int dmalloc(bf16_t** p, size_t elems) { T3_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(p), elems * sizeof(bf16_t))); return 0; }
 
 // ---- the layer stack over `rows` rows whose embeddings are already in e->b->res ----------
+// d_pfx: the shared-prefix page per decode row / per prompt sequence (nullptr without prefix sharing)
 int run_layers(t3_engine* e, int rows, const int32_t* d_pos, const int32_t* d_stream, const int32_t* d_ctx,
-               bool prefill, const int32_t* d_seq_start, const int32_t* d_tiles, int ntiles) {
+               bool prefill, const int32_t* d_seq_start, const int32_t* d_tiles, int ntiles, const int32_t* d_pfx) {
     const t3_config& c = e->cfg;
     const int D = c.d_model, F = c.d_ff, H = c.n_heads, hd = c.head_dim;
     hipStream_t st = e->stream;
@@ -307,9 +349,11 @@ int run_layers(t3_engine* e, int rows, const int32_t* d_pos, const int32_t* d_st
         g.n_valid = 3 * D; g.rope = e->rope; g.pos = d_pos; g.row_stream = d_stream; g.kv = kv; g.layer = li;
         T3_RUN(e, K_QKV, li, WB * 3 * D * D, prefill ? launch_gemm_prompt(EPI_QKV_ROPE, g, st) : launch_gemm(EPI_QKV_ROPE, g, st));
         if (prefill) {
-            T3_RUN(e, K_ATTN_PREFILL, li, 2LL * rows * 4 * D, launch_attn_prefill(e->b->qkv, 3 * D, e->b->att, d_seq_start, d_tiles, ntiles, H, hd, st));
+            T3_RUN(e, K_ATTN_PREFILL, li, 2LL * rows * 4 * D, launch_attn_prefill(e->b->qkv, 3 * D, e->b->att, d_seq_start, d_tiles, ntiles, H, hd, st,
+                                                                                          d_pfx, kCondRows, &kv, li));
         } else {
-            T3_RUN(e, K_ATTN_DECODE, li, e->cur_ctx_tokens * 4LL * D, launch_attn_decode(e->b->qkv, 3 * D, e->b->att, rows, d_stream, d_ctx, kv, li, st));
+            T3_RUN(e, K_ATTN_DECODE, li, e->cur_ctx_tokens * 4LL * D, launch_attn_decode(e->b->qkv, 3 * D, e->b->att, rows, d_stream, d_ctx, kv, li, st,
+                                                                                                     d_pfx, kCondRows));
         }
         GemmArgs o{};
         o.A = e->b->att; o.lda = D; o.Wt = L.wo; o.wscale = L.so; o.C = e->b->res; o.ldc = D; o.M = rows; o.N = D; o.K = D; o.n_valid = D;
@@ -383,6 +427,39 @@ void release_request(t3_engine* e, Request& r) {
         for (int p = 0; p < r.have_pages; ++p)
             e->free_pages.push_back(e->block_table.h[(size_t)(r.slot * e->kv_per_req + u) * e->max_pages + p]);
     e->reserved_unallocated -= (int64_t)(r.reserve_pages - r.have_pages) * e->kv_per_req;
+    if (r.voice >= 0) { e->voices[r.voice].refs--; r.voice = -1; }
+}
+
+// Find the voice entry holding r's conditioning rows, or claim one for them (an unused entry, else the
+// least recently used one that no admitted request reads).  A claimed entry is built by r's prefill step.
+int acquire_voice(t3_engine* e, Request& r) {
+    const size_t n = (size_t)kCondRows * e->cfg.d_model;
+    const uint64_t h = hash_floats(r.cond.data(), n);
+    int pick = -1;
+    for (int v = 0; v < e->n_voices; ++v) {
+        Voice& vc = e->voices[v];
+        if (vc.used && vc.hash == h && std::memcmp(vc.cond.data(), r.cond.data(), n * sizeof(float)) == 0) { pick = v; break; }
+    }
+    if (pick < 0) {
+        for (int v = 0; v < e->n_voices; ++v) {
+            const Voice& vc = e->voices[v];
+            if (vc.refs > 0) continue;
+            if (!vc.used) { pick = v; break; }
+            if (pick < 0 || vc.last_use < e->voices[pick].last_use) pick = v;
+        }
+        if (pick < 0) { t3_set_error("no free shared-prefix entry (max_voices too small)"); return 1; }
+        Voice& vc = e->voices[pick];
+        vc.cond = std::move(r.cond);
+        vc.hash = h;
+        vc.used = true;
+        r.builds_voice = true;
+    }
+    std::vector<float>().swap(r.cond);
+    Voice& vc = e->voices[pick];
+    vc.refs++;
+    vc.last_use = ++e->voice_clock;
+    r.voice = pick;
+    return 0;
 }
 
 // The host table keeps changing while earlier copies may still be queued, so each step uploads
@@ -402,17 +479,39 @@ int run_prefill(t3_engine* e, const std::vector<Request*>& reqs) {
     const t3_config& c = e->cfg;
     t3_engine::Meta& m = e->pm[e->parity];
     const int S = e->rows_per_req, Q = e->kv_per_req, n = (int)reqs.size();
+    const bool share = e->share_prefix;
+    const int first_pos = share ? kCondRows : 0;          // first position a request's own rows cover
     int row = 0, nseq = 0, ntiles = 0, pid = 0;
+    // voices first met in this step: their 34 rows go through the layers as sequences of their own and
+    // leave K/V in the voice page, which the requests' rows read in the same launches
+    if (share)
+        for (int i = 0; i < n; ++i) {
+            Request& r = *reqs[i];
+            if (!r.builds_voice) continue;
+            r.builds_voice = false;
+            const int v = r.voice;
+            T3_HIP_CHECK(hipMemcpyAsync(e->cond_buf + (size_t)v * kCondRows * c.d_model, e->voices[v].cond.data(),
+                                        sizeof(float) * kCondRows * c.d_model, hipMemcpyHostToDevice, e->stream));
+            m.seq_start[nseq] = row; m.seq_pfx[nseq] = -1;
+            m.tiles[2 * ntiles] = nseq; m.tiles[2 * ntiles + 1] = 0; ++ntiles;
+            for (int p = 0; p < kCondRows; ++p, ++row) {
+                m.row_stream[row] = e->n_streams + v; m.row_pos[row] = p; m.row_ctx[row] = p + 1;
+                m.ekind[row] = 0; m.eidx[row] = p; m.eaux[row] = v;
+            }
+            ++nseq;
+        }
     for (int i = 0; i < n; ++i) {
         Request& r = *reqs[i];
         const int T = (int)r.text.size(), P = r.prompt_len;
         if (grow_pages(e, r, P)) return 1;
-        T3_HIP_CHECK(hipMemcpyAsync(e->cond_buf + (size_t)r.slot * kCondRows * c.d_model, r.cond.data(),
-                                    sizeof(float) * kCondRows * c.d_model, hipMemcpyHostToDevice, e->stream));
+        if (!share)
+            T3_HIP_CHECK(hipMemcpyAsync(e->cond_buf + (size_t)r.slot * kCondRows * c.d_model, r.cond.data(),
+                                        sizeof(float) * kCondRows * c.d_model, hipMemcpyHostToDevice, e->stream));
         for (int u = 0; u < Q; ++u) {
             m.seq_start[nseq] = row;
-            for (int q0 = 0; q0 < P; q0 += 64) { m.tiles[2 * ntiles] = nseq; m.tiles[2 * ntiles + 1] = q0; ++ntiles; }
-            for (int p = 0; p < P; ++p, ++row) {
+            m.seq_pfx[nseq] = share ? (int32_t)(e->n_pages + r.voice) : -1;
+            for (int q0 = 0; q0 < P - first_pos; q0 += 64) { m.tiles[2 * ntiles] = nseq; m.tiles[2 * ntiles + 1] = q0; ++ntiles; }
+            for (int p = first_pos; p < P; ++p, ++row) {
                 m.row_stream[row] = r.slot * Q + u;
                 m.row_pos[row] = p;
                 m.row_ctx[row] = p + 1;
@@ -470,7 +569,8 @@ int run_prefill(t3_engine* e, const std::vector<Request*>& reqs) {
         T3_HIP_CHECK(hipMemsetAsync(e->b->att + (size_t)first_ghost * c.d_model, 0,
                                     sizeof(bf16_t) * (size_t)(rows - first_ghost) * c.d_model, e->stream));
     if (run_layers(e, rows, dev_of(m.i32, m.row_pos), dev_of(m.i32, m.row_stream), dev_of(m.i32, m.row_ctx), true,
-                   dev_of(m.i32, m.seq_start), dev_of(m.i32, m.tiles), ntiles)) return 1;
+                   dev_of(m.i32, m.seq_start), dev_of(m.i32, m.tiles), ntiles,
+                   share ? dev_of(m.i32, m.seq_pfx) : nullptr)) return 1;
     if (run_head_and_sample(e, m, n * S, dev_of(m.i32, m.a_rows), n)) return 1;
     e->stats.prefill_requests = n;
     e->stats.prefill_rows = rows;
@@ -488,7 +588,7 @@ int enqueue_decode(t3_engine* e, t3_engine::Meta& m, int B) {
     ea.speech_emb = e->speech_emb; ea.speech_pos = e->speech_pos; ea.last_token = e->last_token; ea.sos_id = kSOS;
     T3_RUN(e, K_EMBED, -1, 2LL * rows * c.d_model, launch_embed(ea, e->stream));
     if (run_layers(e, rows, dev_of(m.i32, m.row_pos), dev_of(m.i32, m.row_stream), dev_of(m.i32, m.row_ctx), false,
-                   nullptr, nullptr, 0)) return 1;
+                   nullptr, nullptr, 0, e->share_prefix ? dev_of(m.i32, m.row_pfx) : nullptr)) return 1;
     return run_head_and_sample(e, m, rows, nullptr, B);
 }
 
@@ -496,6 +596,8 @@ int run_decode(t3_engine* e, const std::vector<Request*>& reqs) {
     const int S = e->rows_per_req, Q = e->kv_per_req, B = (int)reqs.size();
     t3_engine::Meta& m = e->dm[e->parity];
     int64_t ctx_total = 0;
+    std::vector<char> voice_met(e->n_voices, 0);
+    int voices_met = 0;
     for (int i = 0; i < B; ++i) {
         Request& r = *reqs[i];
         const int pos = r.prompt_len + r.n_launched - 1;      // position of the token fed this step
@@ -506,14 +608,18 @@ int run_decode(t3_engine* e, const std::vector<Request*>& reqs) {
             m.row_stream[row] = ghost ? -1 : r.slot * Q + u;
             m.row_pos[row] = pos;
             m.row_ctx[row] = ghost ? 0 : pos + 1;
+            m.row_pfx[row] = (e->share_prefix && !ghost) ? (int32_t)(e->n_pages + r.voice) : -1;
             m.ekind[row] = 4; m.eidx[row] = r.slot; m.eaux[row] = 0;
             if (!ghost) ctx_total += pos + 1;
         }
+        if (e->share_prefix && !voice_met[r.voice]) { voice_met[r.voice] = 1; ++voices_met; }
         m.row_c[i] = i * S;
         m.row_u[i] = S == 2 ? i * S + 1 : -1;
         fill_sampling(m, i, r);
     }
-    e->cur_ctx_tokens = ctx_total;
+    // with shared prefixes the rows of a voice fetch its 34 positions once between them
+    e->cur_ctx_tokens = !e->share_prefix ? ctx_total
+                                         : ctx_total - (int64_t)kCondRows * B * e->kv_per_req + (int64_t)kCondRows * voices_met;
     if (sync_block_table(e)) return 1;
     if (upload(e, m)) return 1;
     e->kphase = 0;
@@ -587,14 +693,22 @@ extern "C" int t3_engine_create(const t3_config* cfg, t3_engine** out) {
     // KV pool
     e->n_pages = c.kv_pages > 0 ? c.kv_pages : (int64_t)e->n_streams * e->max_pages;
     T3_REQUIRE(e->n_pages >= (int64_t)e->kv_per_req * e->max_pages, "kv_pages cannot hold one full request");
+    // shared prefixes: one page each behind the request pages; more entries than slots, so that one is always free
+    T3_REQUIRE(c.prefix_sharing == 0 || c.prefix_sharing == 1, "prefix_sharing must be 0 or 1");
+    T3_REQUIRE(c.max_voices >= 0, "max_voices must not be negative");
+    e->share_prefix = c.prefix_sharing != 0;
+    e->n_voices = !e->share_prefix ? 0 : std::max(c.max_voices, c.max_num_seqs + 1);
+    e->voices.resize(e->n_voices);
     const int64_t page_elems = 2LL * c.n_heads * T3_PAGE * c.head_dim;
-    e->layer_stride = e->n_pages * page_elems;
+    e->layer_stride = (e->n_pages + e->n_voices) * page_elems;
     const size_t pool_elems = (size_t)e->layer_stride * c.n_layers;
     if (dmalloc(&e->kv_pool, pool_elems)) return 1;
     T3_HIP_CHECK(hipMemsetAsync(e->kv_pool, 0, pool_elems * sizeof(bf16_t), e->stream));
     e->free_pages.reserve(e->n_pages);
     for (int64_t p = e->n_pages - 1; p >= 0; --p) e->free_pages.push_back((int32_t)p);
-    if (e->block_table.alloc((size_t)e->n_streams * e->max_pages)) return 1;
+    if (e->block_table.alloc((size_t)(e->n_streams + e->n_voices) * e->max_pages)) return 1;
+    for (int v = 0; v < e->n_voices; ++v)
+        e->block_table.h[(size_t)(e->n_streams + v) * e->max_pages] = (int32_t)(e->n_pages + v);
 
     // activations
     const int prefill_rows = c.max_prefill_rows * e->kv_per_req + (e->uncond_ghost ? c.max_num_seqs : 0);
@@ -613,7 +727,8 @@ extern "C" int t3_engine_create(const t3_config* cfg, t3_engine** out) {
         T3_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&e->bt_stage[q]), sizeof(int32_t) * e->block_table.n));
         T3_HIP_CHECK(hipEventCreateWithFlags(&e->step_done[q], hipEventDisableTiming));
     }
-    T3_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->cond_buf), sizeof(float) * c.max_num_seqs * kCondRows * c.d_model));
+    T3_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->cond_buf),
+                           sizeof(float) * std::max(c.max_num_seqs, e->n_voices) * kCondRows * c.d_model));
     T3_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->seen), (size_t)c.max_num_seqs * kSeenStride));
     T3_HIP_CHECK(hipMemsetAsync(e->seen, 0, (size_t)c.max_num_seqs * kSeenStride, e->stream));
     T3_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->last_token), sizeof(int32_t) * c.max_num_seqs));
@@ -950,6 +1065,7 @@ extern "C" int t3_engine_step(t3_engine* e, int64_t* out_req_ids, int32_t* out_t
         row_budget -= r.prompt_len;
         e->reserved_unallocated += need;
         r.slot = slot;
+        if (e->share_prefix && acquire_voice(e, r)) return 1;
         admitted.push_back(&r);
         e->slots[slot] = std::move(e->waiting.front());
         e->waiting.pop_front();

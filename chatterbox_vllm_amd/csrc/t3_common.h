@@ -119,11 +119,15 @@ int launch_repack(const bf16_t* w, bf16_t* wt, int N, int K, hipStream_t st);
 int launch_quantize(const bf16_t* w, uint8_t* wq, float* scale, int N, int K, hipStream_t st);
 int launch_add_rmsnorm(const bf16_t* x, bf16_t* res, const bf16_t* w, bf16_t* xn, int rows, int d,
                        float eps, hipStream_t st);
+// row_pfx (optional): per row, the page that holds positions [0, npfx) of its stream (shared prefix), or -1
 int launch_attn_decode(const bf16_t* qkv, int ldq, bf16_t* out, int rows, const int32_t* row_stream,
-                       const int32_t* row_ctx, const KvView& kv, int layer, hipStream_t st);
-// tiles_dev: (sequence index, first query row) per 64-row query tile
+                       const int32_t* row_ctx, const KvView& kv, int layer, hipStream_t st,
+                       const int32_t* row_pfx = nullptr, int npfx = 0);
+// tiles_dev: (sequence index, first query row) per 64-row query tile.  seq_pfx_dev (optional): per sequence, the
+// pool page holding keys [0, npfx) when the sequence's rows start at position npfx, or -1 (rows start at 0)
 int launch_attn_prefill(const bf16_t* qkv, int ldq, bf16_t* out, const int32_t* seq_start_dev,
-                        const int32_t* tiles_dev, int ntiles, int H, int hd, hipStream_t st);
+                        const int32_t* tiles_dev, int ntiles, int H, int hd, hipStream_t st,
+                        const int32_t* seq_pfx_dev = nullptr, int npfx = 0, const KvView* kv = nullptr, int layer = 0);
 
 struct EmbedArgs {
     bf16_t* out; int d;                 // [rows, d]

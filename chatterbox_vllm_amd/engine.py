@@ -78,7 +78,8 @@ class T3Engine:
                  max_model_len: int = 1000, max_num_seqs: int = 32, cfg_scale: Optional[float] = None,
                  cfg_paired: Optional[bool] = None, device: int = 0, enforce_eager: bool = False,
                  kv_pages: int = 0, max_prefill_rows: int = 2048, quantization: Optional[str] = None,
-                 scheduling_policy: str = "fcfs", uncond_attends: bool = True, **_ignored_vllm_kwargs):
+                 scheduling_policy: str = "fcfs", uncond_attends: bool = True, prefix_sharing: bool = True,
+                 max_voices: int = 0, **_ignored_vllm_kwargs):
         if cfg_scale is None:                      # models/t3/t3.py:343
             cfg_scale = float(os.environ.get("CHATTERBOX_CFG_SCALE", "0.5"))
         if cfg_paired is None:
@@ -92,6 +93,9 @@ class T3Engine:
         # uncond_attends=False: the uncond half is a context-free row (zero attention output at every layer, no KV),
         # the arithmetic a serving stack performs when it attends only the rows its scheduler counted
         self.uncond_attends = bool(uncond_attends)
+        # prefix_sharing: the K/V of the 34 conditioning positions are computed once per distinct cond_emb and shared by
+        # both streams of a request and by all requests of that voice; ids and logits are bit-identical either way
+        self.prefix_sharing = bool(prefix_sharing)
         self.device = int(device)
         if quantization not in (None, "int8"):
             raise ValueError(f"unsupported quantization {quantization!r}: None or 'int8' (W8A16, per output channel)")
@@ -104,7 +108,7 @@ class T3Engine:
             speech_pos_rows=m.speech_pos_rows, max_model_len=self.max_model_len, max_num_seqs=self.max_num_seqs,
             cfg_paired=(1 if self.uncond_attends else 2) if self.cfg_paired else 0, max_prefill_rows=int(max_prefill_rows), device=self.device,
             use_graphs=int(not enforce_eager), weight_int8=int(quantization == "int8"), cfg_scale=self.cfg_scale, rms_eps=m.rms_eps,
-            kv_pages=int(kv_pages))
+            kv_pages=int(kv_pages), prefix_sharing=int(self.prefix_sharing), max_voices=int(max_voices))
         self._h = C.c_void_p()
         _capi.check(self._lib, self._lib.t3_engine_create(C.byref(cfg), C.byref(self._h)))
         if scheduling_policy not in ("fcfs", "longest_first"):

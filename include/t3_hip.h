@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define T3_ABI_VERSION 1
+#define T3_ABI_VERSION 2
 
 typedef struct t3_engine t3_engine;
 
@@ -48,6 +48,12 @@ typedef struct t3_config {
     float cfg_scale;           /* CHATTERBOX_CFG_SCALE, models/t3/t3.py:343           */
     float rms_eps;
     int64_t kv_pages;          /* KV pool size in 64-token pages; 0 = no oversubscription */
+    int32_t prefix_sharing;    /* 1: the K/V of positions 0..33 (the conditioning rows, t3.py:229-240: the same in
+                                  the cond and uncond stream and in every request of one voice) are computed once
+                                  per distinct conditioning tensor and kept in a page of their own; ids and logits
+                                  are bit-identical to 0.  (The reference defeats vLLM's prefix cache with a random
+                                  hash, t3.py:286-289.)                                                          */
+    int32_t max_voices;        /* distinct conditioning tensors kept; raised to max_num_seqs + 1 if smaller       */
 } t3_config;
 
 /* Per-request sampling parameters: the vllm.SamplingParams fields set at

@@ -146,6 +146,47 @@ def test_ids_do_not_depend_on_batch_or_scheduling(small):
         assert run(1, True, [i])[0][0] == base[i]           # alone
 
 
+@pytest.mark.parametrize("paired,uncond_attends", [(True, True), (True, False), (False, True)])
+def test_shared_prefix_gives_the_bits_of_private_prefixes(small, paired, uncond_attends):
+    """Prefix sharing computes the K/V of the 34 conditioning positions once per voice and lets every stream of
+    that voice read them from one page.  Nothing else changes, so ids AND logits equal those of an engine in
+    which every stream prefills its own copy, bit for bit: with more voices than entries (eviction and rebuild),
+    voices returning after eviction, prompts on both sides of a 64-position tile edge, and slots reused."""
+    cfg, sd = small
+    ns = (1, 28, 29, 30, 70, 5, 93, 12, 40, 3)            # prompt lengths 34 + n + 3: 64 falls at n = 27
+    texts = [_text(n, 300 + n) for n in ns]
+    voices = [0, 1, 0, 2, 3, 4, 1, 5, 0, 2]               # 6 voices through max_num_seqs + 1 = 4 entries
+    sp = SamplingParams(temperature=0.0, repetition_penalty=2.0, max_tokens=40, stop_token_ids=[STOP])
+
+    def run(share):
+        eng = T3Engine(cfg, sd, max_model_len=256, max_num_seqs=3, cfg_scale=3.0, cfg_paired=paired,
+                       uncond_attends=uncond_attends, prefix_sharing=share)
+        out = _run_with_logits(eng, _items(texts, voices), sp)
+        rows = []
+        eng.set_timing(True)                               # synchronous steps: stats() describes the step just run
+        eng.add_request(texts[4], W.synthetic_cond_emb(9), sp)
+        eng.add_request(texts[6], W.synthetic_cond_emb(9), sp)
+        while eng.has_unfinished():
+            eng.step()
+            rows.append(eng.stats().prefill_rows)
+        eng.shutdown()
+        return out, max(rows)
+
+    (ids_s, logits_s, fin_s), rows_s = run(True)
+    (ids_p, logits_p, fin_p), rows_p = run(False)
+    assert ids_s == ids_p and fin_s == fin_p
+    for a, b in zip(logits_s, logits_p):
+        assert len(a) == len(b) == 39
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    # two prompts of one new voice: private = streams x (P1 + P2) rows, shared = 34 + streams x (P1 - 34 + P2 - 34)
+    streams = 2 if (paired and uncond_attends) else 1
+    ghosts = 2 if (paired and not uncond_attends) else 0
+    P1, P2 = 34 + len(texts[4]) + 1, 34 + len(texts[6]) + 1
+    assert rows_p == streams * (P1 + P2) + ghosts
+    assert rows_s == 34 + streams * (P1 + P2 - 68) + ghosts
+
+
 def test_stop_and_length_rules(small):
     cfg, sd = small
     text = _text(6, 7)

@@ -165,8 +165,38 @@ extern "C" int t3_op_attn_decode(const void* qkv_dev, void* out_dev, int32_t row
                               stream_dev, ctx_dev, kv, layer, static_cast<hipStream_t>(stream));
 }
 
+extern "C" int t3_op_attn_decode_prefix(const void* qkv_dev, void* out_dev, int32_t rows, int32_t H, int32_t hd,
+                                        const int32_t* stream_dev, const int32_t* ctx_dev, const void* kv_pool_dev,
+                                        int64_t layer_stride_elems, int32_t layer, const int32_t* block_table_dev,
+                                        int32_t max_pages, const int32_t* prefix_page_dev, int32_t n_prefix, void* stream) {
+    T3_REQUIRE(qkv_dev && out_dev && stream_dev && ctx_dev && kv_pool_dev && block_table_dev && prefix_page_dev, "null argument");
+    const KvView kv = make_kv(const_cast<void*>(kv_pool_dev), layer_stride_elems, block_table_dev, max_pages, H, hd);
+    return launch_attn_decode(static_cast<const bf16_t*>(qkv_dev), 3 * H * hd, static_cast<bf16_t*>(out_dev), rows,
+                              stream_dev, ctx_dev, kv, layer, static_cast<hipStream_t>(stream), prefix_page_dev, n_prefix);
+}
+
+static int attn_prefill_op(const void* qkv_dev, void* out_dev, int32_t n_seqs, const int32_t* seq_start_dev,
+                           const int32_t* seq_start_host, int32_t H, int32_t hd, const int32_t* prefix_page_dev,
+                           int32_t n_prefix, const KvView* kv, int32_t layer, void* stream);
+
 extern "C" int t3_op_attn_prefill(const void* qkv_dev, void* out_dev, int32_t n_seqs, const int32_t* seq_start_dev,
                                   const int32_t* seq_start_host, int32_t H, int32_t hd, void* stream) {
+    return attn_prefill_op(qkv_dev, out_dev, n_seqs, seq_start_dev, seq_start_host, H, hd, nullptr, 0, nullptr, 0, stream);
+}
+
+extern "C" int t3_op_attn_prefill_prefix(const void* qkv_dev, void* out_dev, int32_t n_seqs, const int32_t* seq_start_dev,
+                                         const int32_t* seq_start_host, int32_t H, int32_t hd,
+                                         const int32_t* prefix_page_dev, int32_t n_prefix, const void* kv_pool_dev,
+                                         int64_t layer_stride_elems, int32_t layer, void* stream) {
+    T3_REQUIRE(prefix_page_dev && kv_pool_dev, "null argument");
+    const KvView kv = make_kv(const_cast<void*>(kv_pool_dev), layer_stride_elems, nullptr, 0, H, hd);
+    return attn_prefill_op(qkv_dev, out_dev, n_seqs, seq_start_dev, seq_start_host, H, hd, prefix_page_dev, n_prefix, &kv,
+                           layer, stream);
+}
+
+static int attn_prefill_op(const void* qkv_dev, void* out_dev, int32_t n_seqs, const int32_t* seq_start_dev,
+                           const int32_t* seq_start_host, int32_t H, int32_t hd, const int32_t* prefix_page_dev,
+                           int32_t n_prefix, const KvView* kv, int32_t layer, void* stream) {
     T3_REQUIRE(qkv_dev && out_dev && seq_start_dev && seq_start_host && n_seqs >= 1, "null argument");
     hipStream_t st = static_cast<hipStream_t>(stream);
     std::vector<int32_t> tiles;
@@ -178,7 +208,8 @@ extern "C" int t3_op_attn_prefill(const void* qkv_dev, void* out_dev, int32_t n_
     T3_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_tiles), tiles.size() * sizeof(int32_t)));
     T3_HIP_CHECK(hipMemcpy(d_tiles, tiles.data(), tiles.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     const int rc = launch_attn_prefill(static_cast<const bf16_t*>(qkv_dev), 3 * H * hd, static_cast<bf16_t*>(out_dev),
-                                       seq_start_dev, d_tiles, (int)tiles.size() / 2, H, hd, st);
+                                       seq_start_dev, d_tiles, (int)tiles.size() / 2, H, hd, st, prefix_page_dev, n_prefix,
+                                       kv, layer);
     const hipError_t se = hipStreamSynchronize(st);
     (void)hipFree(d_tiles);
     if (rc) return rc;

@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 from dataclasses import dataclass, field
 from typing import Callable, Dict, Iterable, List, Optional, Sequence, Union
 
@@ -70,8 +71,9 @@ _FINISH = {1: "stop", 2: "length"}
 
 
 class T3Engine:
-    """One engine per GPU.  Not re-entrant: ``generate`` calls must not overlap (the
-    reference's ``LLM.generate`` has the same contract)."""
+    """One engine per GPU.  ``generate`` calls from several threads (the reference's server calls it from
+    worker threads without a lock, openai_tts_server.py:501, 661) are serialised here: one call runs its
+    requests dry before the next starts."""
 
     def __init__(self, model_config: T3ModelConfig, state_dict: Dict[str, torch.Tensor],
                  tokenizer: Optional[Callable[..., List[int]]] = None, *,
@@ -116,6 +118,7 @@ class T3Engine:
         self.scheduling_policy = scheduling_policy
         _capi.check(self._lib, self._lib.t3_engine_set_schedule_policy(self._h, int(scheduling_policy == "longest_first")))
         self._next_id = 0
+        self._generate_lock = threading.Lock()
         self._load(state_dict)
 
     # ---- weights -----------------------------------------------------------------
@@ -220,6 +223,10 @@ class T3Engine:
         sps = list(sampling_params) if isinstance(sampling_params, (list, tuple)) else [sampling_params] * n
         if len(sps) != n:
             raise ValueError("one SamplingParams per request item is required")
+        with self._generate_lock:
+            return self._generate_locked(request_items, sps, on_step)
+
+    def _generate_locked(self, request_items, sps, on_step) -> List[RequestOutput]:
         outs: List[RequestOutput] = []
         by_id: Dict[int, RequestOutput] = {}
         added: List[int] = []

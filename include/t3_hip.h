@@ -236,6 +236,20 @@ int t3_op_attn_decode(const void* qkv_dev, void* out_dev, int32_t rows, int32_t 
 /* Causal attention inside packed prompt rows: sequence i owns rows [seq_start[i], seq_start[i+1]). */
 int t3_op_attn_prefill(const void* qkv_dev, void* out_dev, int32_t n_seqs, const int32_t* seq_start_dev,
                        const int32_t* seq_start_host, int32_t H, int32_t hd, void* stream);
+/* The two attention forms with a shared prefix (the engine's prefix_sharing mode; no counterpart in the reference,
+ * which keeps vLLM's prefix cache from matching, models/t3/t3.py:286-289).
+ * Decode: where prefix_page_dev[r] >= 0, positions [0, n_prefix) of row r are read from that page of the pool
+ * instead of page 0 of the row's own stream (1 <= n_prefix <= 64); the bits equal those of a private copy.
+ * Prefill: where prefix_page_dev[i] >= 0, the rows of sequence i are positions n_prefix, n_prefix + 1, ... and
+ * keys [0, n_prefix) come from that page (layout as written by t3_op_gemm_qkv_rope); -1 = a sequence from position 0. */
+int t3_op_attn_decode_prefix(const void* qkv_dev, void* out_dev, int32_t rows, int32_t H, int32_t hd,
+                             const int32_t* stream_dev, const int32_t* ctx_dev, const void* kv_pool_dev,
+                             int64_t layer_stride_elems, int32_t layer, const int32_t* block_table_dev,
+                             int32_t max_pages, const int32_t* prefix_page_dev, int32_t n_prefix, void* stream);
+int t3_op_attn_prefill_prefix(const void* qkv_dev, void* out_dev, int32_t n_seqs, const int32_t* seq_start_dev,
+                              const int32_t* seq_start_host, int32_t H, int32_t hd, const int32_t* prefix_page_dev,
+                              int32_t n_prefix, const void* kv_pool_dev, int64_t layer_stride_elems, int32_t layer,
+                              void* stream);
 /* logits rows (bf16 [*, ldl]) -> CFG combine, +1000 offset, repetition penalty over seen_dev
  * ([n, seen_stride] bytes, column space), greedy argmax (lowest index wins ties).
  * row_c/row_u: logits row of the cond / uncond stream per request (row_u < 0: no CFG). */

@@ -260,6 +260,84 @@ def test_attn_prefill_is_causal_per_sequence(capi):
         assert_bf16_close(out[s0:s0 + L], ref, max_frac=0.05, what=f"attn_prefill len={L}")
 
 
+def test_attn_decode_with_shared_prefix_page_has_the_bits_of_private_copies(capi):
+    """Positions [0, 34) of some rows live in one shared page; the row's own page 0 holds garbage there."""
+    H, hd, NP = 16, 64, 34
+    ctxs = [35, 63, 64, 65, 200, 513, 1000, 34, 100]
+    shared = [True, True, False, True, True, False, True, True, True]
+    n, max_pages = len(ctxs), 16
+    pool, bt, layer_stride = _kv_setup(n + 1, max_pages, 2, seed=5)     # stream n owns the prefix page
+    pool.copy_(_rand(tuple(pool.shape), 22, 3.0))
+    pk, pv = _rand((NP, H, hd), 90).to(DEV), _rand((NP, H, hd), 91).to(DEV)
+    for layer in (0, 1):
+        _fill_cache(pool, layer_stride, layer, bt, n, pk, pv)
+    private = pool.clone()
+    for s, c in enumerate(ctxs):
+        k, v = _rand((c, H, hd), 130 + s).to(DEV), _rand((c, H, hd), 160 + s).to(DEV)
+        if shared[s]:
+            k[:NP], v[:NP] = pk, pv
+        _fill_cache(private, layer_stride, 1, bt, s, k, v)
+        if shared[s]:                                                    # own copy of the prefix positions: garbage
+            k, v = k.clone(), v.clone()
+            k[:NP], v[:NP] = _rand((NP, H, hd), 7).to(DEV) * 50, _rand((NP, H, hd), 8).to(DEV) * 50
+        _fill_cache(pool, layer_stride, 1, bt, s, k, v)
+    qkv = torch.zeros(n, 3 * H * hd, dtype=torch.bfloat16, device=DEV)
+    qkv[:, : H * hd] = _rand((n, H * hd), 23).to(DEV)
+    stream_d = torch.arange(n, dtype=torch.int32, device=DEV)
+    ctx_d = torch.tensor(ctxs, dtype=torch.int32, device=DEV)
+    bt_d = bt.to(DEV)
+    pfx_d = torch.tensor([int(bt[n, 0]) if sh else -1 for sh in shared], dtype=torch.int32, device=DEV)
+    want = torch.zeros(n, H * hd, dtype=torch.bfloat16, device=DEV)
+    got = torch.zeros_like(want)
+    call(capi, "t3_op_attn_decode", p(qkv), p(want), n, H, hd, p(stream_d), p(ctx_d), p(private), layer_stride, 1,
+         p(bt_d), max_pages, None)
+    call(capi, "t3_op_attn_decode_prefix", p(qkv), p(got), n, H, hd, p(stream_d), p(ctx_d), p(pool), layer_stride, 1,
+         p(bt_d), max_pages, p(pfx_d), NP, None)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+
+
+def test_attn_prefill_with_shared_prefix_page_has_the_bits_of_whole_sequences(capi):
+    """Sequences whose first 34 keys come from a pool page equal the tail rows of the whole sequences."""
+    H, hd, NP = 16, 64, 34
+    D = H * hd
+    tails = [1, 29, 30, 31, 100, 230]                                   # rows after the prefix; 34 + 30 = one key tile
+    n_pages, layer = 3, 1
+    layer_stride = n_pages * 2 * H * 64 * hd
+    pool = (_rand((2 * layer_stride,), 24, 3.0)).to(DEV)
+    page = 2
+    pre = _rand((NP, 3 * D), 41).to(DEV)                                # q|k|v rows of the prefix positions
+    view = pool[layer * layer_stride:(layer + 1) * layer_stride].view(-1, 2, H, 64, hd)
+    view[page, 0, :, :NP, :] = pre[:, D:2 * D].view(NP, H, hd).transpose(0, 1)
+    view[page, 1, :, :NP, :] = pre[:, 2 * D:].view(NP, H, hd).transpose(0, 1)
+    rows = [_rand((t, 3 * D), 50 + i).to(DEV) for i, t in enumerate(tails)]
+    # whole sequences (prefix rows + tail rows), and one sequence that has no prefix at all
+    whole = torch.cat([torch.cat([pre, r]) for r in rows] + [rows[4]])
+    ws = [0]
+    for t in tails:
+        ws.append(ws[-1] + NP + t)
+    ws.append(ws[-1] + tails[4])
+    want = torch.zeros(whole.shape[0], D, dtype=torch.bfloat16, device=DEV)
+    ws_h = torch.tensor(ws, dtype=torch.int32)
+    ws_d = ws_h.to(DEV)
+    call(capi, "t3_op_attn_prefill", p(whole), p(want), len(ws) - 1, p(ws_d), C.cast(ws_h.data_ptr(), C.POINTER(C.c_int32)),
+         H, hd, None)
+    part = torch.cat(rows + [rows[4]])
+    ps = [0]
+    for t in tails + [tails[4]]:
+        ps.append(ps[-1] + t)
+    got = torch.zeros(part.shape[0], D, dtype=torch.bfloat16, device=DEV)
+    ps_h = torch.tensor(ps, dtype=torch.int32)
+    ps_d = ps_h.to(DEV)
+    pfx_d = torch.tensor([page] * len(tails) + [-1], dtype=torch.int32, device=DEV)
+    call(capi, "t3_op_attn_prefill_prefix", p(part), p(got), len(ps) - 1, p(ps_d), C.cast(ps_h.data_ptr(), C.POINTER(C.c_int32)),
+         H, hd, p(pfx_d), NP, p(pool), layer_stride, layer, None)
+    torch.cuda.synchronize()
+    for i in range(len(tails)):
+        assert torch.equal(got[ps[i]:ps[i + 1]], want[ws[i] + NP:ws[i + 1]]), f"sequence {i}"
+    assert torch.equal(got[ps[-2]:], want[ws[-2]:])
+
+
 def test_sampler_cfg_penalty_argmax_is_exact(capi):
     from oracle.t3_oracle import T3Oracle
     n, vocab, ldl = 6, 8194, 8208

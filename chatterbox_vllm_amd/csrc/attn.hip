@@ -8,7 +8,9 @@
 
 // K and V are read once per step and never again before ~1 GB of other traffic: nontemporal loads
 // keep them from displacing the step's activations in L2 (measured: 12 % less time per launch).
+#ifndef ATT_LOAD
 #define ATT_LOAD(p) __builtin_nontemporal_load(p)
+#endif
 #ifndef ATT_NW
 #define ATT_NW 8          // waves per workgroup in the decode kernel
 #endif

@@ -373,6 +373,55 @@ def test_small_kv_pool_and_prompt_row_budget_only_delay_requests(small):
     eng.shutdown()
 
 
+def test_random_arrivals_aborts_and_voices_leave_ids_and_pool_intact(small):
+    """Scheduler fuzz: requests of 11 voices arrive over time, a few are aborted while waiting or in flight, the
+    pool is smaller than the slot count needs and the shared-prefix table has fewer entries than there are voices.
+    Every request that was not aborted ends with the ids it produces alone; at the end every page is free."""
+    import random
+    cfg, sd = small
+    rng = random.Random(5)
+    n = 36
+    texts = [_text(rng.choice([2, 5, 9, 26, 27, 28, 40, 77]), 800 + i) for i in range(n)]
+    voices = [rng.randrange(11) for _ in range(n)]              # the table holds max_num_seqs + 1 = 7
+    lens = [rng.choice([1, 2, 7, 19, 33, 48]) for _ in range(n)]
+    arrive = sorted(rng.randrange(60) for _ in range(n))
+    abort_at = {i: arrive[i] + rng.randrange(0, 12) for i in rng.sample(range(n), 8)}
+    sps = [SamplingParams(temperature=0.0, repetition_penalty=2.0, max_tokens=m, stop_token_ids=[STOP]) for m in lens]
+    conds = [W.synthetic_cond_emb(v) for v in range(11)]
+
+    solo = T3Engine(cfg, sd, max_model_len=192, max_num_seqs=1, cfg_scale=3.0, prefix_sharing=False, enforce_eager=True)
+    want = [solo.generate({"prompt_token_ids": texts[i], "multi_modal_data": {"conditionals": [conds[voices[i]]]}},
+                          sps[i])[0].outputs[0].token_ids for i in range(n) if i not in abort_at]
+    solo.shutdown()
+
+    pool = 5 * 2 * 3 + 2                                    # five and a bit full-length requests for six slots
+    eng = T3Engine(cfg, sd, max_model_len=192, max_num_seqs=6, cfg_scale=3.0, kv_pages=pool, max_voices=3)
+    got, rid_of, done, aborted = {}, {}, set(), set()
+    step, nxt = 0, 0
+    while nxt < n or eng.has_unfinished():
+        while nxt < n and arrive[nxt] <= step:
+            rid_of[nxt] = eng.add_request(texts[nxt], conds[voices[nxt]], sps[nxt])
+            got[rid_of[nxt]] = []
+            nxt += 1
+        for i, at in abort_at.items():
+            if at == step and i in rid_of and rid_of[i] not in done and rid_of[i] not in aborted:
+                eng.abort(rid_of[i])
+                aborted.add(rid_of[i])
+        for rid, tok, fin in eng.step():
+            assert rid not in aborted or len(got[rid]) < 48
+            got[rid].append(tok)
+            if fin is not None:
+                done.add(rid)
+        st = eng.stats()
+        assert 0 <= st.free_pages <= pool and st.running <= 6
+        step += 1
+        assert step < 5000
+    kept = [i for i in range(n) if i not in abort_at]
+    assert [got[rid_of[i]] for i in kept] == want
+    assert eng.stats().free_pages == pool
+    eng.shutdown()
+
+
 def test_full_size_job_rows_do_not_depend_on_the_batch():
     """BASELINE's full sizes (30 layers, 32 CFG-paired slots, contexts up to max_model_len 1000) are out of the
     CPU oracle's reach, so the property checked here is size-independent: a request's ids inside the loaded

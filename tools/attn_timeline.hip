@@ -17,7 +17,8 @@ void t3_set_error(const std::string& msg) { fprintf(stderr, "error: %s\n", msg.c
 int main(int argc, char** argv) {
     const int rows = argc > 1 ? atoi(argv[1]) : 64;
     const int sorted = argc > 2 ? atoi(argv[2]) : 0;       // 1: rows in descending context order
-    const int H = 16, hd = 64, max_pages = 16, L = 12, layers = 12;
+    const int H = 16, hd = 64, max_pages = 16, L = 12;
+    const int layers = argc > 3 ? atoi(argv[3]) : 12;       // 1: every launch re-reads the same K/V (cache-resident)
     const int n_streams = rows;
     const int64_t n_pages = (int64_t)n_streams * max_pages;
     const int64_t page_elems = 2LL * H * T3_PAGE * hd;

@@ -14,6 +14,12 @@
 // slot/page release.  Sampled ids stay on the device (last_token[slot]) and feed the next
 // step's embedding gather; the host only reads them for stop detection and output.
 //
+// Prefill and decode of one step run side by side: the prompts of newly admitted requests go through the layers on
+// a second stream with their own activation buffers while the running requests decode on the main stream (the two
+// touch different KV pages, slots and sampler rows; both chains are latency-bound, so about half of the prefill time
+// disappears behind the decode step).  The prefill stream starts behind everything already queued on the main stream
+// (so behind the block-table upload and the previous step), and the step's completion event waits for both.
+//
 // Steps are pipelined one deep: a call to t3_engine_step launches step k+1 and only then waits
 // for step k and reports its tokens, so the GPU always has the next step queued while the host
 // does its bookkeeping.  Step k+1 is planned before step k's tokens are known: length limits are
@@ -131,7 +137,12 @@ struct Pinned {
 
 struct t3_engine {
     t3_config cfg{};
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;                       // main stream: decode steps, block-table uploads, step events
+    hipStream_t pstream = nullptr;                      // prefill of the step's admissions (== stream in the synchronous modes)
+    hipStream_t pstream_own = nullptr;                  // the second stream itself
+    hipStream_t cur = nullptr;                          // the stream the phase being enqueued uses
+    hipEvent_t fork_ev[2] = {nullptr, nullptr}, join_ev[2] = {nullptr, nullptr};
+    bool overlap_prefill = true;
     int rows_per_req = 1;                               // rows a request contributes to a step (2 with CFG pairing)
     int kv_per_req = 1;                                 // KV streams a request owns (2 when the uncond stream attends)
     bool uncond_ghost = false;                          // cfg_paired == 2: the uncond row gets no attention and no KV
@@ -160,7 +171,7 @@ struct t3_engine {
     struct Bufs {
         bf16_t *res = nullptr, *xn = nullptr, *qkv = nullptr, *att = nullptr, *hbuf = nullptr, *logits = nullptr;
         float* slab = nullptr;                          // [GEMM_SLAB_SPLIT][rows][d] fp32 split-K partials (decode)
-    } bufs;
+    } bufs, pbufs;                                      // decode rows / prompt rows
     Bufs* b = &bufs;
     int max_rows = 0;
     int64_t cur_ctx_tokens = 0;                         // positions of K/V the decode rows being enqueued must fetch: sum of
@@ -268,15 +279,15 @@ int meta_alloc(t3_engine::Meta& m, size_t rows, size_t reqs, size_t prompt_ids) 
 template <typename T> T* dev_of(const Pinned<T>& p, const T* host_view) { return p.d + (host_view - p.h); }
 
 int upload(t3_engine* e, t3_engine::Meta& m) {
-    T3_HIP_CHECK(hipMemcpyAsync(m.i32.d, m.i32.h, sizeof(int32_t) * m.i32.n, hipMemcpyHostToDevice, e->stream));
-    T3_HIP_CHECK(hipMemcpyAsync(m.f32.d, m.f32.h, sizeof(float) * m.f32.n, hipMemcpyHostToDevice, e->stream));
-    T3_HIP_CHECK(hipMemcpyAsync(m.u64.d, m.u64.h, sizeof(uint64_t) * m.u64.n, hipMemcpyHostToDevice, e->stream));
+    T3_HIP_CHECK(hipMemcpyAsync(m.i32.d, m.i32.h, sizeof(int32_t) * m.i32.n, hipMemcpyHostToDevice, e->cur));
+    T3_HIP_CHECK(hipMemcpyAsync(m.f32.d, m.f32.h, sizeof(float) * m.f32.n, hipMemcpyHostToDevice, e->cur));
+    T3_HIP_CHECK(hipMemcpyAsync(m.u64.d, m.u64.h, sizeof(uint64_t) * m.u64.n, hipMemcpyHostToDevice, e->cur));
     return 0;
 }
 
 int stage_check(t3_engine* e, const char* label, int layer) {
     if (!e->debug_sync) return 0;
-    const hipError_t err = hipStreamSynchronize(e->stream);
+    const hipError_t err = hipStreamSynchronize(e->cur);
     if (err != hipSuccess) {
         t3_set_error(std::string("stage ") + label + (layer >= 0 ? " layer " + std::to_string(layer) : std::string()) +
                      ": " + hipGetErrorString(err));
@@ -331,7 +342,7 @@ int run_layers(t3_engine* e, int rows, const int32_t* d_pos, const int32_t* d_st
                bool prefill, const int32_t* d_seq_start, const int32_t* d_tiles, int ntiles, const int32_t* d_pfx) {
     const t3_config& c = e->cfg;
     const int D = c.d_model, F = c.d_ff, H = c.n_heads, hd = c.head_dim;
-    hipStream_t st = e->stream;
+    hipStream_t st = e->cur;
     const KvView kv = e->kvview();
     const long long WB = c.weight_int8 ? 1 : 2;          // bytes per projection weight (algorithmic-bytes accounting)
     // decode rows: the normalised activations and the MLP hidden rows travel in activation tile order (t3_common.h),
@@ -380,7 +391,7 @@ int run_head_and_sample(t3_engine* e, t3_engine::Meta& m, int head_rows, const i
     g.A = e->b->xn; g.lda = c.d_model; g.a_rows = d_a_rows; g.a_tiled = d_a_rows == nullptr;   // decode: tile-ordered xn
     g.Wt = e->head; g.C = e->b->logits; g.ldc = e->head_n;
     g.M = head_rows; g.N = e->head_n; g.K = c.d_model; g.n_valid = e->head_n;
-    T3_RUN(e, K_HEAD, -1, 2LL * e->head_n * c.d_model, launch_gemm(EPI_STORE, g, e->stream));
+    T3_RUN(e, K_HEAD, -1, 2LL * e->head_n * c.d_model, launch_gemm(EPI_STORE, g, e->cur));
     SampleArgs s{};
     s.logits = e->b->logits; s.ldl = e->head_n; s.vocab = c.speech_vocab;
     s.row_c = dev_of(m.i32, m.row_c); s.row_u = dev_of(m.i32, m.row_u); s.slot = dev_of(m.i32, m.slot);
@@ -391,7 +402,7 @@ int run_head_and_sample(t3_engine* e, t3_engine::Meta& m, int head_rows, const i
     s.seen = e->seen; s.seen_stride = kSeenStride; s.last_token = e->last_token;
     s.out_tokens = dev_of(m.i32, m.out_tokens);
     s.out_logits = e->keep_logits ? e->dbg_logits : nullptr;
-    T3_RUN(e, K_SAMPLE, -1, 4LL * n_req * c.speech_vocab, launch_sample(s, e->stream));
+    T3_RUN(e, K_SAMPLE, -1, 4LL * n_req * c.speech_vocab, launch_sample(s, e->cur));
     return 0;
 }
 
@@ -474,6 +485,15 @@ int sync_block_table(t3_engine* e) {
     return 0;
 }
 
+// The prefill stream waits for what has been enqueued on the main stream up to now (nothing to do when the two
+// are one stream).
+int prefill_after_main(t3_engine* e) {
+    if (e->pstream == e->stream) return 0;
+    T3_HIP_CHECK(hipEventRecord(e->fork_ev[e->parity], e->stream));
+    T3_HIP_CHECK(hipStreamWaitEvent(e->pstream, e->fork_ev[e->parity], 0));
+    return 0;
+}
+
 // ---- prefill of newly admitted requests ------------------------------------------------
 int run_prefill(t3_engine* e, const std::vector<Request*>& reqs) {
     const t3_config& c = e->cfg;
@@ -482,6 +502,10 @@ int run_prefill(t3_engine* e, const std::vector<Request*>& reqs) {
     const bool share = e->share_prefix;
     const int first_pos = share ? kCondRows : 0;          // first position a request's own rows cover
     int row = 0, nseq = 0, ntiles = 0, pid = 0;
+    // the prompts run on the prefill stream, behind everything the main stream holds so far
+    e->cur = e->pstream;
+    e->b = &e->pbufs;
+    if (prefill_after_main(e)) return 1;
     // voices first met in this step: their 34 rows go through the layers as sequences of their own and
     // leave K/V in the voice page, which the requests' rows read in the same launches
     if (share)
@@ -491,7 +515,7 @@ int run_prefill(t3_engine* e, const std::vector<Request*>& reqs) {
             r.builds_voice = false;
             const int v = r.voice;
             T3_HIP_CHECK(hipMemcpyAsync(e->cond_buf + (size_t)v * kCondRows * c.d_model, e->voices[v].cond.data(),
-                                        sizeof(float) * kCondRows * c.d_model, hipMemcpyHostToDevice, e->stream));
+                                        sizeof(float) * kCondRows * c.d_model, hipMemcpyHostToDevice, e->cur));
             m.seq_start[nseq] = row; m.seq_pfx[nseq] = -1;
             m.tiles[2 * ntiles] = nseq; m.tiles[2 * ntiles + 1] = 0; ++ntiles;
             for (int p = 0; p < kCondRows; ++p, ++row) {
@@ -506,7 +530,7 @@ int run_prefill(t3_engine* e, const std::vector<Request*>& reqs) {
         if (grow_pages(e, r, P)) return 1;
         if (!share)
             T3_HIP_CHECK(hipMemcpyAsync(e->cond_buf + (size_t)r.slot * kCondRows * c.d_model, r.cond.data(),
-                                        sizeof(float) * kCondRows * c.d_model, hipMemcpyHostToDevice, e->stream));
+                                        sizeof(float) * kCondRows * c.d_model, hipMemcpyHostToDevice, e->cur));
         for (int u = 0; u < Q; ++u) {
             m.seq_start[nseq] = row;
             m.seq_pfx[nseq] = share ? (int32_t)(e->n_pages + r.voice) : -1;
@@ -548,7 +572,8 @@ int run_prefill(t3_engine* e, const std::vector<Request*>& reqs) {
         }
     const int rows = row;
     e->kphase = 1;
-    if (sync_block_table(e)) return 1;
+    if (sync_block_table(e)) return 1;                    // on the main stream
+    if (prefill_after_main(e)) return 1;
     if (upload(e, m)) return 1;
     if (stage_check(e, "prefill_upload")) return 1;
     // seen rows
@@ -556,7 +581,7 @@ int run_prefill(t3_engine* e, const std::vector<Request*>& reqs) {
     for (int i = 0; i < n; ++i) {
         const int len = reqs[i]->prompt_len;
         T3_RUN(e, K_SEEN, -1, (int64_t)kSeenStride, launch_seen_init(e->seen + (size_t)reqs[i]->slot * kSeenStride, kSeenStride,
-                                                     dev_of(m.i32, m.prompt_ids) + pid, len, e->stream));
+                                                     dev_of(m.i32, m.prompt_ids) + pid, len, e->cur));
         pid += len;
     }
     EmbedArgs ea{};
@@ -564,16 +589,18 @@ int run_prefill(t3_engine* e, const std::vector<Request*>& reqs) {
     ea.kind = dev_of(m.i32, m.ekind); ea.idx = dev_of(m.i32, m.eidx); ea.aux = dev_of(m.i32, m.eaux);
     ea.cond = e->cond_buf; ea.text_emb = e->text_emb; ea.text_pos = e->text_pos;
     ea.speech_emb = e->speech_emb; ea.speech_pos = e->speech_pos; ea.last_token = e->last_token; ea.sos_id = kSOS;
-    T3_RUN(e, K_EMBED, -1, 2LL * rows * c.d_model, launch_embed(ea, e->stream));
+    T3_RUN(e, K_EMBED, -1, 2LL * rows * c.d_model, launch_embed(ea, e->cur));
     if (rows > first_ghost)
         T3_HIP_CHECK(hipMemsetAsync(e->b->att + (size_t)first_ghost * c.d_model, 0,
-                                    sizeof(bf16_t) * (size_t)(rows - first_ghost) * c.d_model, e->stream));
+                                    sizeof(bf16_t) * (size_t)(rows - first_ghost) * c.d_model, e->cur));
     if (run_layers(e, rows, dev_of(m.i32, m.row_pos), dev_of(m.i32, m.row_stream), dev_of(m.i32, m.row_ctx), true,
                    dev_of(m.i32, m.seq_start), dev_of(m.i32, m.tiles), ntiles,
                    share ? dev_of(m.i32, m.seq_pfx) : nullptr)) return 1;
     if (run_head_and_sample(e, m, n * S, dev_of(m.i32, m.a_rows), n)) return 1;
     e->stats.prefill_requests = n;
     e->stats.prefill_rows = rows;
+    e->cur = e->stream;
+    e->b = &e->bufs;
     return 0;
 }
 
@@ -586,7 +613,7 @@ int enqueue_decode(t3_engine* e, t3_engine::Meta& m, int B) {
     ea.kind = dev_of(m.i32, m.ekind); ea.idx = dev_of(m.i32, m.eidx); ea.aux = dev_of(m.i32, m.eaux);
     ea.cond = e->cond_buf; ea.text_emb = e->text_emb; ea.text_pos = e->text_pos;
     ea.speech_emb = e->speech_emb; ea.speech_pos = e->speech_pos; ea.last_token = e->last_token; ea.sos_id = kSOS;
-    T3_RUN(e, K_EMBED, -1, 2LL * rows * c.d_model, launch_embed(ea, e->stream));
+    T3_RUN(e, K_EMBED, -1, 2LL * rows * c.d_model, launch_embed(ea, e->cur));
     if (run_layers(e, rows, dev_of(m.i32, m.row_pos), dev_of(m.i32, m.row_stream), dev_of(m.i32, m.row_ctx), false,
                    nullptr, nullptr, 0, e->share_prefix ? dev_of(m.i32, m.row_pfx) : nullptr)) return 1;
     return run_head_and_sample(e, m, rows, nullptr, B);
@@ -685,6 +712,9 @@ extern "C" int t3_engine_create(const t3_config* cfg, t3_engine** out) {
     e->max_pages = pages_for(c.max_model_len);
     e->head_n = (c.speech_vocab + 15) / 16 * 16;
     T3_HIP_CHECK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    T3_HIP_CHECK(hipStreamCreateWithFlags(&e->pstream_own, hipStreamNonBlocking));
+    e->pstream = e->pstream_own;
+    e->cur = e->stream;
     e->layers.resize(c.n_layers);
     e->slots.resize(c.max_num_seqs);
     const char* dbg = getenv("T3_DEBUG_SYNC");
@@ -713,9 +743,9 @@ extern "C" int t3_engine_create(const t3_config* cfg, t3_engine** out) {
     // activations
     const int prefill_rows = c.max_prefill_rows * e->kv_per_req + (e->uncond_ghost ? c.max_num_seqs : 0);
     e->max_rows = (std::max(prefill_rows, e->n_rows) + 127) / 128 * 128;   // whole row tiles for the tile-ordered buffers
-    {
-        const size_t R = (size_t)e->max_rows, RD = (size_t)e->n_rows;
-        t3_engine::Bufs& b = e->bufs;
+    for (int which = 0; which < 2; ++which) {             // decode rows, prompt rows
+        const size_t R = (size_t)((which == 0 ? e->n_rows : prefill_rows) + 127) / 128 * 128, RD = (size_t)e->n_rows;
+        t3_engine::Bufs& b = which == 0 ? e->bufs : e->pbufs;
         if (dmalloc(&b.res, R * c.d_model) || dmalloc(&b.xn, R * c.d_model) || dmalloc(&b.qkv, R * 3 * c.d_model) ||
             dmalloc(&b.att, R * c.d_model) || dmalloc(&b.hbuf, R * c.d_ff) || dmalloc(&b.logits, RD * e->head_n)) return 1;
         T3_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&b.slab), sizeof(float) * GEMM_SLAB_SPLIT * R * c.d_model));
@@ -723,9 +753,12 @@ extern "C" int t3_engine_create(const t3_config* cfg, t3_engine** out) {
     e->b = &e->bufs;
     if (const char* ug = getenv("T3_USE_GRAPHS")) e->cfg.use_graphs = atoi(ug) != 0;
     if (const char* as = getenv("T3_ASYNC")) e->async_steps = atoi(as) != 0;
+    if (const char* ov = getenv("T3_OVERLAP_PREFILL")) e->overlap_prefill = atoi(ov) != 0;
     for (int q = 0; q < 2; ++q) {
         T3_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&e->bt_stage[q]), sizeof(int32_t) * e->block_table.n));
         T3_HIP_CHECK(hipEventCreateWithFlags(&e->step_done[q], hipEventDisableTiming));
+        T3_HIP_CHECK(hipEventCreateWithFlags(&e->fork_ev[q], hipEventDisableTiming));
+        T3_HIP_CHECK(hipEventCreateWithFlags(&e->join_ev[q], hipEventDisableTiming));
     }
     T3_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->cond_buf),
                            sizeof(float) * std::max(c.max_num_seqs, e->n_voices) * kCondRows * c.d_model));
@@ -846,7 +879,8 @@ extern "C" int t3_engine_finalize(t3_engine* e) {
 extern "C" int t3_engine_destroy(t3_engine* e) {
     if (!e) return 0;
     (void)hipSetDevice(e->cfg.device);
-    (void)hipStreamSynchronize(e->stream);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    if (e->pstream_own) (void)hipStreamSynchronize(e->pstream_own);
     for (auto& kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
     for (auto& kv : e->raw) (void)hipFree(kv.second.p);
     for (auto& L : e->layers) {
@@ -854,8 +888,8 @@ extern "C" int t3_engine_destroy(t3_engine* e) {
         (void)hipFree(L.sqkv); (void)hipFree(L.so); (void)hipFree(L.sgu); (void)hipFree(L.sd);
     }
     (void)hipFree(e->head); (void)hipFree(e->kv_pool);
-    {
-        auto& b = e->bufs;
+    for (auto* bp : {&e->bufs, &e->pbufs}) {
+        auto& b = *bp;
         (void)hipFree(b.res); (void)hipFree(b.xn); (void)hipFree(b.qkv); (void)hipFree(b.att); (void)hipFree(b.hbuf);
         (void)hipFree(b.logits); (void)hipFree(b.slab);
     }
@@ -863,12 +897,15 @@ extern "C" int t3_engine_destroy(t3_engine* e) {
     for (int q = 0; q < 2; ++q) {
         if (e->bt_stage[q]) (void)hipHostFree(e->bt_stage[q]);
         if (e->step_done[q]) (void)hipEventDestroy(e->step_done[q]);
+        if (e->fork_ev[q]) (void)hipEventDestroy(e->fork_ev[q]);
+        if (e->join_ev[q]) (void)hipEventDestroy(e->join_ev[q]);
     }
     e->block_table.release();
     for (auto* m : {&e->dm[0], &e->dm[1], &e->pm[0], &e->pm[1]}) { m->i32.release(); m->f32.release(); m->u64.release(); }
     for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
     for (auto& ev : e->kpool) (void)hipEventDestroy(ev);
-    (void)hipStreamDestroy(e->stream);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    if (e->pstream_own) (void)hipStreamDestroy(e->pstream_own);
     delete e;
     return 0;
 }
@@ -1072,13 +1109,20 @@ extern "C" int t3_engine_step(t3_engine* e, int64_t* out_req_ids, int32_t* out_t
     }
 
     const int q = e->parity;
+    // the measuring and debugging modes keep everything on one stream
+    hipStream_t ps = (sync_mode || !e->overlap_prefill) ? e->stream : e->pstream_own;
+    if (ps != e->pstream) {                                // mode switch: nothing is in flight here (reported above)
+        T3_HIP_CHECK(hipStreamSynchronize(e->pstream_own));
+        e->pstream = ps;
+    }
     if (!admitted.empty()) {
         if (e->timing) T3_HIP_CHECK(hipEventRecord(e->ev[0], e->stream));
         if (run_prefill(e, admitted)) return 1;
         if (e->timing) T3_HIP_CHECK(hipEventRecord(e->ev[1], e->stream));
         T3_HIP_CHECK(hipMemcpyAsync(e->pm[q].out_tokens, dev_of(e->pm[q].i32, e->pm[q].out_tokens),
-                                    sizeof(int32_t) * admitted.size(), hipMemcpyDeviceToHost, e->stream));
+                                    sizeof(int32_t) * admitted.size(), hipMemcpyDeviceToHost, e->pstream));
         for (Request* r : admitted) r->n_launched = 1;
+        if (e->pstream != e->stream) T3_HIP_CHECK(hipEventRecord(e->join_ev[q], e->pstream));
     }
     if (!running.empty()) {
         if (e->timing) T3_HIP_CHECK(hipEventRecord(e->ev[2], e->stream));
@@ -1089,6 +1133,7 @@ extern "C" int t3_engine_step(t3_engine* e, int64_t* out_req_ids, int32_t* out_t
         for (Request* r : running) r->n_launched++;
     }
     const bool launched = !admitted.empty() || !running.empty();
+    if (!admitted.empty() && e->pstream != e->stream) T3_HIP_CHECK(hipStreamWaitEvent(e->stream, e->join_ev[q], 0));
     if (launched) T3_HIP_CHECK(hipEventRecord(e->step_done[q], e->stream));
 
     // report the previous step while this one runs (in the synchronous modes it was reported above)

@@ -14,11 +14,14 @@
 // slot/page release.  Sampled ids stay on the device (last_token[slot]) and feed the next
 // step's embedding gather; the host only reads them for stop detection and output.
 //
-// Prefill and decode of one step run side by side: the prompts of newly admitted requests go through the layers on
-// a second stream with their own activation buffers while the running requests decode on the main stream (the two
-// touch different KV pages, slots and sampler rows; both chains are latency-bound, so about half of the prefill time
-// disappears behind the decode step).  The prefill stream starts behind everything already queued on the main stream
-// (so behind the block-table upload and the previous step), and the step's completion event waits for both.
+// Prefill runs beside decode: the prompts of newly admitted requests go through the layers on a second stream with
+// their own activation buffers, as one prefill job, while the running requests keep decoding on the main stream (the
+// two touch different KV pages, slots and sampler rows, and both chains are latency-bound, so most of the prefill
+// time disappears behind the decode steps).  The job starts behind everything already queued on the main stream (the
+// block-table upload, the step in flight); the main stream never waits for it: a step call polls the job's event,
+// reports its first tokens once it has completed and only then lets its requests join the decode rows.  One job is
+// outstanding at a time; admission pauses until it has been reported.  The measuring and debugging modes keep
+// prefill inside the step, on the main stream.
 //
 // Steps are pipelined one deep: a call to t3_engine_step launches step k+1 and only then waits
 // for step k and reports its tokens, so the GPU always has the next step queued while the host
@@ -84,6 +87,7 @@ struct Request {
     int reserve_pages = 0;            // worst-case pages per stream
     int have_pages = 0;               // pages allocated per stream
     bool aborted = false;
+    bool prefilling = false;          // admitted into a prefill job that has not been reported yet
     int voice = -1;                   // shared-prefix entry this request reads positions 0..33 from
     bool builds_voice = false;        // its prefill step also carries the voice's 34 rows
 };
@@ -141,7 +145,10 @@ struct t3_engine {
     hipStream_t pstream = nullptr;                      // prefill of the step's admissions (== stream in the synchronous modes)
     hipStream_t pstream_own = nullptr;                  // the second stream itself
     hipStream_t cur = nullptr;                          // the stream the phase being enqueued uses
-    hipEvent_t fork_ev[2] = {nullptr, nullptr}, join_ev[2] = {nullptr, nullptr};
+    hipEvent_t fork_ev[2] = {nullptr, nullptr};
+    // the prefill job that has been launched on the prefill stream and not yet reported
+    struct PrefillJob { bool valid = false; int parity = 0; std::vector<Request*> reqs; } pjob;
+    hipEvent_t pjob_done = nullptr;
     bool overlap_prefill = true;
     int rows_per_req = 1;                               // rows a request contributes to a step (2 with CFG pairing)
     int kv_per_req = 1;                                 // KV streams a request owns (2 when the uncond stream attends)
@@ -758,7 +765,7 @@ extern "C" int t3_engine_create(const t3_config* cfg, t3_engine** out) {
         T3_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&e->bt_stage[q]), sizeof(int32_t) * e->block_table.n));
         T3_HIP_CHECK(hipEventCreateWithFlags(&e->step_done[q], hipEventDisableTiming));
         T3_HIP_CHECK(hipEventCreateWithFlags(&e->fork_ev[q], hipEventDisableTiming));
-        T3_HIP_CHECK(hipEventCreateWithFlags(&e->join_ev[q], hipEventDisableTiming));
+
     }
     T3_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->cond_buf),
                            sizeof(float) * std::max(c.max_num_seqs, e->n_voices) * kCondRows * c.d_model));
@@ -773,6 +780,7 @@ extern "C" int t3_engine_create(const t3_config* cfg, t3_engine** out) {
         if (meta_alloc(e->pm[q], prefill_rows, c.max_num_seqs, (size_t)c.max_prefill_rows + (size_t)c.max_num_seqs * 64)) return 1;
     }
     for (auto& ev : e->ev) T3_HIP_CHECK(hipEventCreate(&ev));
+    T3_HIP_CHECK(hipEventCreateWithFlags(&e->pjob_done, hipEventDisableTiming));
     T3_HIP_CHECK(hipStreamSynchronize(e->stream));
     *out = e.release();
     return 0;
@@ -898,11 +906,12 @@ extern "C" int t3_engine_destroy(t3_engine* e) {
         if (e->bt_stage[q]) (void)hipHostFree(e->bt_stage[q]);
         if (e->step_done[q]) (void)hipEventDestroy(e->step_done[q]);
         if (e->fork_ev[q]) (void)hipEventDestroy(e->fork_ev[q]);
-        if (e->join_ev[q]) (void)hipEventDestroy(e->join_ev[q]);
+
     }
     e->block_table.release();
     for (auto* m : {&e->dm[0], &e->dm[1], &e->pm[0], &e->pm[1]}) { m->i32.release(); m->f32.release(); m->u64.release(); }
     for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
+    if (e->pjob_done) (void)hipEventDestroy(e->pjob_done);
     for (auto& ev : e->kpool) (void)hipEventDestroy(ev);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     if (e->pstream_own) (void)hipStreamDestroy(e->pstream_own);
@@ -972,7 +981,7 @@ extern "C" int t3_engine_abort(t3_engine* e, int64_t req_id) {
 
 extern "C" int t3_engine_has_unfinished(t3_engine* e) {
     if (!e) return 0;
-    if (!e->waiting.empty() || e->inflight.valid) return 1;
+    if (!e->waiting.empty() || e->inflight.valid || e->pjob.valid) return 1;
     for (auto& s : e->slots) if (s) return 1;
     return 0;
 }
@@ -1032,6 +1041,42 @@ extern "C" int t3_engine_last_logits(t3_engine* e, int64_t req_id, float* out) {
 
 namespace {
 
+// One computed token of request r: count it, apply the finish rules, free the request's slot and pages when it ends.
+void account_token(t3_engine* e, Request* r, int32_t tok, int64_t* out_req_ids, int32_t* out_tokens, int32_t* out_finished,
+                   int& k) {
+    if (r->zombie) {                                          // its token is past a stop or an abort: drop it
+        release_request(e, *r); e->slots[r->slot].reset();
+        return;
+    }
+    r->n_out++;
+    int fin = 0;
+    if (tok == r->sp.stop_token) fin = 1;
+    else if (r->n_out >= r->limit) fin = 2;
+    out_req_ids[k] = r->id; out_tokens[k] = tok; out_finished[k] = fin; ++k;
+    if (!fin) return;
+    if (r->n_launched > r->n_out) r->zombie = true;           // the next step already carries it
+    else { release_request(e, *r); e->slots[r->slot].reset(); }
+}
+
+// Wait for the outstanding prefill job and report the first token of each of its requests; they may decode from now on.
+int report_prefill_job(t3_engine* e, int64_t* out_req_ids, int32_t* out_tokens, int32_t* out_finished, int32_t cap,
+                       int32_t* n_out) {
+    t3_engine::PrefillJob& j = e->pjob;
+    if (!j.valid) return 0;
+    T3_REQUIRE(*n_out + (int)j.reqs.size() <= cap, "output arrays too small");
+    T3_HIP_CHECK(hipEventSynchronize(e->pjob_done));
+    j.valid = false;
+    int k = *n_out;
+    const int32_t* pt = e->pm[j.parity].out_tokens;
+    for (size_t i = 0; i < j.reqs.size(); ++i) {
+        j.reqs[i]->prefilling = false;
+        account_token(e, j.reqs[i], pt[i], out_req_ids, out_tokens, out_finished, k);
+    }
+    j.reqs.clear();
+    *n_out = k;
+    return 0;
+}
+
 // Wait for the launched step and report it: one (request, token, finish reason) triple per row it carried.
 int report_inflight(t3_engine* e, int64_t* out_req_ids, int32_t* out_tokens, int32_t* out_finished, int32_t cap,
                     int32_t* n_out) {
@@ -1046,24 +1091,10 @@ int report_inflight(t3_engine* e, int64_t* out_req_ids, int32_t* out_tokens, int
         if (!f.running.empty()) T3_HIP_CHECK(hipEventElapsedTime(&e->stats.decode_gpu_ms, e->ev[2], e->ev[3]));
     }
     int k = *n_out;
-    auto account = [&](Request* r, int32_t tok) {
-        if (r->zombie) {                                      // its token is past a stop or an abort: drop it
-            release_request(e, *r); e->slots[r->slot].reset();
-            return;
-        }
-        r->n_out++;
-        int fin = 0;
-        if (tok == r->sp.stop_token) fin = 1;
-        else if (r->n_out >= r->limit) fin = 2;
-        out_req_ids[k] = r->id; out_tokens[k] = tok; out_finished[k] = fin; ++k;
-        if (!fin) return;
-        if (r->n_launched > r->n_out) r->zombie = true;       // the next step already carries it
-        else { release_request(e, *r); e->slots[r->slot].reset(); }
-    };
     const int32_t* pt = e->pm[f.parity].out_tokens;
     const int32_t* dt = e->dm[f.parity].out_tokens;
-    for (size_t i = 0; i < f.admitted.size(); ++i) account(f.admitted[i], pt[i]);
-    for (size_t i = 0; i < f.running.size(); ++i) account(f.running[i], dt[i]);
+    for (size_t i = 0; i < f.admitted.size(); ++i) account_token(e, f.admitted[i], pt[i], out_req_ids, out_tokens, out_finished, k);
+    for (size_t i = 0; i < f.running.size(); ++i) account_token(e, f.running[i], dt[i], out_req_ids, out_tokens, out_finished, k);
     *n_out = k;
     return 0;
 }
@@ -1082,16 +1113,34 @@ extern "C" int t3_engine_step(t3_engine* e, int64_t* out_req_ids, int32_t* out_t
     // a synchronous step must not be planned on stale knowledge: report the launched one first
     if (sync_mode && report_inflight(e, out_req_ids, out_tokens, out_finished, cap, n_out)) return 1;
 
+    // A prefill job on the second stream: report it once it has completed (or when the GPU has nothing else to do);
+    // a switch to a synchronous mode finishes it first.
+    const bool overlap = !sync_mode && e->overlap_prefill;
+    if (e->pjob.valid) {
+        bool report = !overlap;
+        if (!report) {
+            const hipError_t qs = hipEventQuery(e->pjob_done);
+            if (qs != hipSuccess && qs != hipErrorNotReady) T3_HIP_CHECK(qs);
+            report = qs == hipSuccess;
+            if (!report) {                                    // nothing decoding and nothing in flight: wait for it
+                bool busy = e->inflight.valid;
+                for (auto& s : e->slots) busy = busy || (s && !s->prefilling && !s->zombie && s->n_launched < s->limit);
+                report = !busy;
+            }
+        }
+        if (report && report_prefill_job(e, out_req_ids, out_tokens, out_finished, cap, n_out)) return 1;
+    }
+
     // requests with tokens still to launch decode; new ones prefill
     std::vector<Request*> running, admitted;
     for (auto& s : e->slots)
-        if (s && !s->zombie && s->n_launched < s->limit) running.push_back(s.get());
+        if (s && !s->zombie && !s->prefilling && s->n_launched < s->limit) running.push_back(s.get());
     std::sort(running.begin(), running.end(), [](const Request* a, const Request* b) {
         const int ca = a->prompt_len + a->n_launched, cb = b->prompt_len + b->n_launched;
         return ca != cb ? ca > cb : a->slot < b->slot;
     });
     int row_budget = c.max_prefill_rows;
-    while (!e->waiting.empty()) {
+    while (!e->waiting.empty() && !e->pjob.valid) {
         Request& r = *e->waiting.front();
         int slot = -1;
         for (int i = 0; i < c.max_num_seqs; ++i) if (!e->slots[i]) { slot = i; break; }
@@ -1109,12 +1158,7 @@ extern "C" int t3_engine_step(t3_engine* e, int64_t* out_req_ids, int32_t* out_t
     }
 
     const int q = e->parity;
-    // the measuring and debugging modes keep everything on one stream
-    hipStream_t ps = (sync_mode || !e->overlap_prefill) ? e->stream : e->pstream_own;
-    if (ps != e->pstream) {                                // mode switch: nothing is in flight here (reported above)
-        T3_HIP_CHECK(hipStreamSynchronize(e->pstream_own));
-        e->pstream = ps;
-    }
+    e->pstream = overlap ? e->pstream_own : e->stream;     // no job is outstanding when this changes
     if (!admitted.empty()) {
         if (e->timing) T3_HIP_CHECK(hipEventRecord(e->ev[0], e->stream));
         if (run_prefill(e, admitted)) return 1;
@@ -1122,7 +1166,14 @@ extern "C" int t3_engine_step(t3_engine* e, int64_t* out_req_ids, int32_t* out_t
         T3_HIP_CHECK(hipMemcpyAsync(e->pm[q].out_tokens, dev_of(e->pm[q].i32, e->pm[q].out_tokens),
                                     sizeof(int32_t) * admitted.size(), hipMemcpyDeviceToHost, e->pstream));
         for (Request* r : admitted) r->n_launched = 1;
-        if (e->pstream != e->stream) T3_HIP_CHECK(hipEventRecord(e->join_ev[q], e->pstream));
+        if (overlap) {                                     // a job of its own: reported by a later call, see above
+            T3_HIP_CHECK(hipEventRecord(e->pjob_done, e->pstream));
+            for (Request* r : admitted) r->prefilling = true;
+            e->pjob.valid = true;
+            e->pjob.parity = q;
+            e->pjob.reqs = std::move(admitted);
+            admitted.clear();
+        }
     }
     if (!running.empty()) {
         if (e->timing) T3_HIP_CHECK(hipEventRecord(e->ev[2], e->stream));
@@ -1133,7 +1184,6 @@ extern "C" int t3_engine_step(t3_engine* e, int64_t* out_req_ids, int32_t* out_t
         for (Request* r : running) r->n_launched++;
     }
     const bool launched = !admitted.empty() || !running.empty();
-    if (!admitted.empty() && e->pstream != e->stream) T3_HIP_CHECK(hipStreamWaitEvent(e->stream, e->join_ev[q], 0));
     if (launched) T3_HIP_CHECK(hipEventRecord(e->step_done[q], e->stream));
 
     // report the previous step while this one runs (in the synchronous modes it was reported above)

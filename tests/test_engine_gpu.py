@@ -373,11 +373,14 @@ def test_small_kv_pool_and_prompt_row_budget_only_delay_requests(small):
     eng.shutdown()
 
 
-def test_random_arrivals_aborts_and_voices_leave_ids_and_pool_intact(small):
+@pytest.mark.parametrize("overlap", ["1", "0"])
+def test_random_arrivals_aborts_and_voices_leave_ids_and_pool_intact(small, overlap, monkeypatch):
     """Scheduler fuzz: requests of 11 voices arrive over time, a few are aborted while waiting or in flight, the
     pool is smaller than the slot count needs and the shared-prefix table has fewer entries than there are voices.
-    Every request that was not aborted ends with the ids it produces alone; at the end every page is free."""
+    Every request that was not aborted ends with the ids it produces alone; at the end every page is free.
+    Run with prefill as jobs of their own on the second stream (the default) and with prefill inside the step."""
     import random
+    monkeypatch.setenv("T3_OVERLAP_PREFILL", overlap)     # prefill jobs beside the decode steps / inside the step
     cfg, sd = small
     rng = random.Random(5)
     n = 36

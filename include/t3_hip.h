@@ -104,7 +104,10 @@ int t3_engine_add_request(t3_engine* e, int64_t req_id, const int32_t* text_ids,
  * 2 length.  Tokens are in the +1000 id space, the stop token is reported.
  * Iterations are pipelined one deep: a call launches the next iteration and reports the
  * previous one, so a call may report nothing (the first after admission) and, when a
- * measuring mode has just been switched on, two iterations' triples in order; give
+ * measuring mode has just been switched on, two iterations' triples in order.  The prompts of
+ * newly admitted requests run beside the decode iterations as a job on a second stream; the
+ * call that finds the job complete reports the first token of each of its requests (before any
+ * later token of theirs), and they decode from the next iteration on.  Give
  * cap >= 2 * max_num_seqs and loop while t3_engine_has_unfinished(). */
 int t3_engine_step(t3_engine* e, int64_t* out_req_ids, int32_t* out_tokens, int32_t* out_finished,
                    int32_t cap, int32_t* n_out);

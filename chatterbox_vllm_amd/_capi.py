@@ -129,6 +129,9 @@ def load() -> C.CDLL:
     if not os.path.isfile(path):
         raise T3Error(f"{path} not found: build it with `make -C chatterbox_vllm_amd/csrc` "
                       "(or __graft_entry__.build()); there is no fallback path")
+    # PyTorch-ROCm ships its own HIP / HSA runtime.  Loading it first makes this library bind to that same copy;
+    # the other order puts two runtimes into the process and the second one finds no device.
+    import torch  # noqa: F401
     lib = C.CDLL(path)
     for name, (argtypes, restype) in SIGNATURES.items():
         fn = getattr(lib, name)            # AttributeError here = library does not match the header

@@ -42,7 +42,7 @@ class T3StepStats(C.Structure):
     _fields_ = [
         ("prefill_requests", C.c_int32), ("prefill_rows", C.c_int32), ("decode_requests", C.c_int32),
         ("decode_rows", C.c_int32), ("decode_ctx_tokens", C.c_int64), ("free_pages", C.c_int32),
-        ("waiting", C.c_int32), ("running", C.c_int32), ("reserved0", C.c_int32),
+        ("waiting", C.c_int32), ("running", C.c_int32), ("prefill_outstanding", C.c_int32),
         ("decode_gpu_ms", C.c_float), ("prefill_gpu_ms", C.c_float),
     ]
 

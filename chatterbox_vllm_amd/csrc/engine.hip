@@ -1196,6 +1196,7 @@ extern "C" int t3_engine_step(t3_engine* e, int64_t* out_req_ids, int32_t* out_t
         e->parity ^= 1;
         if (sync_mode && report_inflight(e, out_req_ids, out_tokens, out_finished, cap, n_out)) return 1;
     }
+    e->stats.prefill_outstanding = e->pjob.valid ? (int32_t)e->pjob.reqs.size() : 0;
     e->stats.free_pages = (int32_t)e->free_pages.size();
     e->stats.waiting = (int32_t)e->waiting.size();
     int run = 0;

@@ -71,7 +71,8 @@ typedef struct t3_sampling {
 typedef struct t3_step_stats {
     int32_t prefill_requests, prefill_rows, decode_requests, decode_rows;
     int64_t decode_ctx_tokens; /* sum over decode streams of context length           */
-    int32_t free_pages, waiting, running, reserved0;
+    int32_t free_pages, waiting, running;
+    int32_t prefill_outstanding; /* requests of the prefill job that runs beside the decode steps, 0 = none */
     float decode_gpu_ms;       /* HIP-event time of the decode part, 0 if not timed   */
     float prefill_gpu_ms;
 } t3_step_stats;

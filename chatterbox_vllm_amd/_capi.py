@@ -61,6 +61,8 @@ class T3GemmDesc(C.Structure):
         ("rope_dev", C.c_void_p), ("pos_dev", C.c_void_p), ("stream_dev", C.c_void_p), ("kv_pool_dev", C.c_void_p),
         ("layer_stride_elems", C.c_int64), ("block_table_dev", C.c_void_p),
         ("a_tiled", C.c_int32), ("out_tiled", C.c_int32),
+        ("fn_slab_dev", C.c_void_p), ("fn_res_in_dev", C.c_void_p), ("fn_res_out_dev", C.c_void_p),
+        ("fn_norm_w_dev", C.c_void_p), ("fn_nsplit", C.c_int32), ("fn_eps", C.c_float),
     ]
 
 

@@ -122,7 +122,7 @@ extern "C" int t3_op_quantize_weight(const void* w_dev, void* wq_dev, float* sca
 }
 
 extern "C" int t3_op_gemm_ex(const t3_gemm_desc* d, void* stream) {
-    T3_REQUIRE(d && d->a_dev && d->w_dev, "null argument");
+    T3_REQUIRE(d && (d->a_dev || d->fn_norm_w_dev) && d->w_dev, "null argument");
     T3_REQUIRE(d->epilogue >= 0 && d->epilogue <= 4, "epilogue must be 0..4");
     T3_REQUIRE(!d->prompt_form || d->epilogue >= 2, "the prompt form exists for epilogues 2, 3 and 4");
     T3_REQUIRE(!d->prompt_form || (!d->a_tiled && !d->out_tiled), "the prompt form reads and writes row-major activations");
@@ -131,6 +131,12 @@ extern "C" int t3_op_gemm_ex(const t3_gemm_desc* d, void* stream) {
     g.A = static_cast<const bf16_t*>(d->a_dev); g.lda = d->K; g.Wt = static_cast<const bf16_t*>(d->w_dev);
     g.wscale = d->w_scale_dev; g.C = static_cast<bf16_t*>(d->out_dev); g.M = d->M; g.N = d->N; g.K = d->K;
     g.slab = d->slab_dev; g.a_tiled = d->a_tiled != 0; g.c_tiled = d->out_tiled != 0;
+    if (d->fn_norm_w_dev) {
+        T3_REQUIRE(!d->prompt_form && (d->epilogue == 2 || d->epilogue == 3), "the norm prologue belongs to the streaming forms 2 and 3");
+        g.fn_w = static_cast<const bf16_t*>(d->fn_norm_w_dev); g.fn_eps = d->fn_eps; g.fn_nsplit = d->fn_nsplit;
+        g.fn_slab = d->fn_slab_dev; g.fn_res_in = static_cast<const bf16_t*>(d->fn_res_in_dev);
+        g.fn_res_out = static_cast<bf16_t*>(d->fn_res_out_dev);
+    }
     switch (d->epilogue) {
         case 0: case 1:
             T3_REQUIRE(d->out_dev && d->ldc >= 1, "bad output");

@@ -150,6 +150,7 @@ struct t3_engine {
     struct PrefillJob { bool valid = false; int parity = 0; std::vector<Request*> reqs; } pjob;
     hipEvent_t pjob_done = nullptr;
     bool overlap_prefill = true;
+    bool fused_norm = true;                             // few-row decode steps: norm inside the QKV / gate_up projections
     int rows_per_req = 1;                               // rows a request contributes to a step (2 with CFG pairing)
     int kv_per_req = 1;                                 // KV streams a request owns (2 when the uncond stream attends)
     bool uncond_ghost = false;                          // cfg_paired == 2: the uncond row gets no attention and no KV
@@ -177,6 +178,7 @@ struct t3_engine {
     // activations (shared by prefill and decode: steps execute in stream order)
     struct Bufs {
         bf16_t *res = nullptr, *xn = nullptr, *qkv = nullptr, *att = nullptr, *hbuf = nullptr, *logits = nullptr;
+        bf16_t* res2 = nullptr;                         // second residual buffer of the few-row decode form (GEMM_FUSED_NORM_ROWS rows)
         float* slab = nullptr;                          // [GEMM_SLAB_SPLIT][rows][d] fp32 split-K partials (decode)
     } bufs, pbufs;                                      // decode rows / prompt rows
     Bufs* b = &bufs;
@@ -355,14 +357,26 @@ int run_layers(t3_engine* e, int rows, const int32_t* d_pos, const int32_t* d_st
     // decode rows: the normalised activations and the MLP hidden rows travel in activation tile order (t3_common.h),
     // so every projection operand load is 1 KiB of contiguous memory; prompt rows stay row-major for the LDS-tiled kernels
     const bool tiled = !prefill;
+    // Decode steps of a few rows (a single stream, the tail of a queue) are nothing but launch latency: there the two norm
+    // launches of a layer move into the prologue of the projection that follows them (same arithmetic in the same order,
+    // so the same bits as the separate kernel; gemm.hip).  Every workgroup then reads the residual rows, so the updated
+    // rows go to the other of two buffers.
+    const bool fuse = !prefill && e->fused_norm && rows <= GEMM_FUSED_NORM_ROWS;
+    bf16_t *res = e->b->res, *res_other = e->b->res2;
     for (int li = 0; li < c.n_layers; ++li) {
         const Layer& L = e->layers[li];
         // o_proj / down_proj leave split-K partial slabs, folded in by the next norm kernel.  Prompt rows always
         // take the LDS-tiled kernels and decode rows the weight-streaming ones, whatever the row count, so that
         // a row's bits never depend on what shares its launch.
-        T3_RUN(e, K_NORM, li, 4LL * rows * D, launch_slab_add_rmsnorm(e->b->slab, li > 0 ? GEMM_SLAB_SPLIT : 0, e->b->res, L.ln1,
-                                                                      e->b->xn, rows, D, c.rms_eps, st, tiled));
+        if (!fuse)
+            T3_RUN(e, K_NORM, li, 4LL * rows * D, launch_slab_add_rmsnorm(e->b->slab, li > 0 ? GEMM_SLAB_SPLIT : 0, res, L.ln1,
+                                                                          e->b->xn, rows, D, c.rms_eps, st, tiled));
         GemmArgs g{};
+        if (fuse) {
+            g.fn_w = L.ln1; g.fn_eps = c.rms_eps; g.fn_res_in = res; g.fn_nsplit = li > 0 ? GEMM_SLAB_SPLIT : 0;
+            g.fn_slab = e->b->slab; g.fn_res_out = res_other;
+            if (li > 0) std::swap(res, res_other);
+        }
         g.A = e->b->xn; g.lda = D; g.a_tiled = tiled; g.Wt = L.wqkv; g.wscale = L.sqkv; g.C = e->b->qkv; g.ldc = 3 * D; g.M = rows; g.N = 3 * D; g.K = D;
         g.n_valid = 3 * D; g.rope = e->rope; g.pos = d_pos; g.row_stream = d_stream; g.kv = kv; g.layer = li;
         T3_RUN(e, K_QKV, li, WB * 3 * D * D, prefill ? launch_gemm_prompt(EPI_QKV_ROPE, g, st) : launch_gemm(EPI_QKV_ROPE, g, st));
@@ -377,9 +391,15 @@ int run_layers(t3_engine* e, int rows, const int32_t* d_pos, const int32_t* d_st
         o.A = e->b->att; o.lda = D; o.Wt = L.wo; o.wscale = L.so; o.C = e->b->res; o.ldc = D; o.M = rows; o.N = D; o.K = D; o.n_valid = D;
         o.slab = e->b->slab;
         T3_RUN(e, K_OPROJ, li, WB * D * D, prefill ? launch_gemm_prompt(EPI_SLAB, o, st) : launch_gemm_slab(o, st));
-        T3_RUN(e, K_NORM, li, 4LL * rows * D, launch_slab_add_rmsnorm(e->b->slab, GEMM_SLAB_SPLIT, e->b->res, L.ln2, e->b->xn, rows, D,
-                                                                      c.rms_eps, st, tiled));
+        if (!fuse)
+            T3_RUN(e, K_NORM, li, 4LL * rows * D, launch_slab_add_rmsnorm(e->b->slab, GEMM_SLAB_SPLIT, res, L.ln2, e->b->xn, rows, D,
+                                                                          c.rms_eps, st, tiled));
         GemmArgs u{};
+        if (fuse) {
+            u.fn_w = L.ln2; u.fn_eps = c.rms_eps; u.fn_res_in = res; u.fn_nsplit = GEMM_SLAB_SPLIT;
+            u.fn_slab = e->b->slab; u.fn_res_out = res_other;
+            std::swap(res, res_other);
+        }
         u.A = e->b->xn; u.lda = D; u.a_tiled = tiled; u.c_tiled = tiled; u.Wt = L.wgu; u.wscale = L.sgu; u.C = e->b->hbuf; u.ldc = F; u.M = rows; u.N = 2 * F; u.K = D; u.n_valid = 2 * F;
         T3_RUN(e, K_GATEUP, li, WB * 2 * F * D, prefill ? launch_gemm_prompt(EPI_SILU, u, st) : launch_gemm(EPI_SILU, u, st));
         GemmArgs dn{};
@@ -387,7 +407,7 @@ int run_layers(t3_engine* e, int rows, const int32_t* d_pos, const int32_t* d_st
         dn.slab = e->b->slab;
         T3_RUN(e, K_DOWN, li, WB * F * D, prefill ? launch_gemm_prompt(EPI_SLAB, dn, st) : launch_gemm_slab(dn, st));
     }
-    T3_RUN(e, K_NORM, -1, 4LL * rows * D, launch_slab_add_rmsnorm(e->b->slab, GEMM_SLAB_SPLIT, e->b->res, e->norm_w, e->b->xn, rows, D,
+    T3_RUN(e, K_NORM, -1, 4LL * rows * D, launch_slab_add_rmsnorm(e->b->slab, GEMM_SLAB_SPLIT, res, e->norm_w, e->b->xn, rows, D,
                                                                   c.rms_eps, st, tiled));
     return 0;
 }
@@ -754,13 +774,15 @@ extern "C" int t3_engine_create(const t3_config* cfg, t3_engine** out) {
         const size_t R = (size_t)((which == 0 ? e->n_rows : prefill_rows) + 127) / 128 * 128, RD = (size_t)e->n_rows;
         t3_engine::Bufs& b = which == 0 ? e->bufs : e->pbufs;
         if (dmalloc(&b.res, R * c.d_model) || dmalloc(&b.xn, R * c.d_model) || dmalloc(&b.qkv, R * 3 * c.d_model) ||
-            dmalloc(&b.att, R * c.d_model) || dmalloc(&b.hbuf, R * c.d_ff) || dmalloc(&b.logits, RD * e->head_n)) return 1;
+            dmalloc(&b.att, R * c.d_model) || dmalloc(&b.hbuf, R * c.d_ff) || dmalloc(&b.logits, RD * e->head_n) ||
+            dmalloc(&b.res2, (size_t)16 * c.d_model)) return 1;
         T3_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&b.slab), sizeof(float) * GEMM_SLAB_SPLIT * R * c.d_model));
     }
     e->b = &e->bufs;
     if (const char* ug = getenv("T3_USE_GRAPHS")) e->cfg.use_graphs = atoi(ug) != 0;
     if (const char* as = getenv("T3_ASYNC")) e->async_steps = atoi(as) != 0;
     if (const char* ov = getenv("T3_OVERLAP_PREFILL")) e->overlap_prefill = atoi(ov) != 0;
+    if (const char* fn = getenv("T3_FUSED_NORM")) e->fused_norm = atoi(fn) != 0;
     for (int q = 0; q < 2; ++q) {
         T3_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&e->bt_stage[q]), sizeof(int32_t) * e->block_table.n));
         T3_HIP_CHECK(hipEventCreateWithFlags(&e->step_done[q], hipEventDisableTiming));
@@ -899,7 +921,7 @@ extern "C" int t3_engine_destroy(t3_engine* e) {
     for (auto* bp : {&e->bufs, &e->pbufs}) {
         auto& b = *bp;
         (void)hipFree(b.res); (void)hipFree(b.xn); (void)hipFree(b.qkv); (void)hipFree(b.att); (void)hipFree(b.hbuf);
-        (void)hipFree(b.logits); (void)hipFree(b.slab);
+        (void)hipFree(b.logits); (void)hipFree(b.slab); (void)hipFree(b.res2);
     }
     (void)hipFree(e->cond_buf); (void)hipFree(e->seen); (void)hipFree(e->last_token); (void)hipFree(e->dbg_logits);
     for (int q = 0; q < 2; ++q) {

@@ -42,10 +42,15 @@ __device__ __forceinline__ bf16x8 dequant8(unsigned lo, unsigned hi) {
     return r;
 }
 
-template <int NB, int MT, int KW, int KT, int EPI, bool W8>
+// FN >= 0: residual-add + RMSNorm in the prologue (launches of at most GEMM_FUSED_NORM_ROWS rows, one row tile): wave pair
+// (2r, 2r+1) does for row r what slab_add_rmsnorm_kernel<FN> does with its 128 threads, the normalised row tile goes to LDS
+// in activation tile order and the MFMA operands come from there.  FN is the number of split-K slabs to fold in.
+template <int NB, int MT, int KW, int KT, int EPI, bool W8, int FN = -1>
 __global__ __launch_bounds__(KW * 64) void gemm_stream_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) float red_raw[];
     f32x4* red = reinterpret_cast<f32x4*>(red_raw);
+    __shared__ __attribute__((aligned(16))) bf16_t fn_tile[FN >= 0 ? 16 * 1024 : 8];   // one row tile, all of K
+    __shared__ float fn_part[GEMM_FUSED_NORM_ROWS][2];
     constexpr int NT = NB * MT;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -111,6 +116,20 @@ __global__ __launch_bounds__(KW * 64) void gemm_stream_kernel(GemmArgs a) {
             if (region >= 1) pre_st = a.row_stream[r];
         }
     }
+    // FN: this thread's share of the norm.  Its loads go out ahead of the weight stream (loads complete in order: a wait
+    // for a load issued behind the weights would wait for the weights too); the arithmetic runs underneath that stream.
+    float fz[8];
+    u32x4 fwv = {0u, 0u, 0u, 0u}, frv = {0u, 0u, 0u, 0u};
+    f32x4 fp[FN > 0 ? FN : 1][2];
+    const int frow = w >> 1, ft = (w & 1) * 64 + lane;    // row and thread-of-128 of the norm kernel this thread stands for
+    if constexpr (FN >= 0) {
+        static_assert(FN < 0 || (MT == 1 && KW == 8 && KW * KT * 32 == 1024), "the fused norm is built for one row tile, K = 1024");
+        if (frow < a.M) {
+            frv = *reinterpret_cast<const u32x4*>(a.fn_res_in + (size_t)frow * 1024 + ft * 8);
+            fwv = *reinterpret_cast<const u32x4*>(a.fn_w + ft * 8);
+            norm_load8<(FN > 0 ? FN : 0)>(a.fn_slab + (size_t)frow * 1024 + ft * 8, (size_t)a.M * 1024, fp);
+        }
+    }
     // weight fragments: the HBM stream
     constexpr int NWF = W8 ? 1 : KT, NWQ = W8 ? KT / 2 : 1;
     bf16x8 wf[NB][NWF];
@@ -144,11 +163,33 @@ __global__ __launch_bounds__(KW * 64) void gemm_stream_kernel(GemmArgs a) {
                 pre_page = a.kv.block_table[(size_t)pre_st * a.kv.max_pages + (pre_pos >> 6)];
         }
     }
+    if constexpr (FN >= 0) {
+        float ss = 0.f;
+        if (frow < a.M) {
+            unpack8(frv, fz);
+            norm_sum8<(FN > 0 ? FN : 0)>(fp, fz);
+            if constexpr (FN > 0) {
+                if (blockIdx.x == 0 && blockIdx.y == 0)
+                    *reinterpret_cast<u32x4*>(a.fn_res_out + (size_t)frow * 1024 + ft * 8) = pack8(fz);
+            }
+            ss = wave_sum(norm_ssq8(fz));
+            if (lane == 0) fn_part[frow][w & 1] = ss;
+        }
+        __syncthreads();
+        if (frow < a.M) {
+            const float sc = norm_rstd(fn_part[frow][0] + fn_part[frow][1], a.fn_eps);
+            *reinterpret_cast<u32x4*>(fn_tile + (ft >> 2) * 512 + ((ft & 3) * 16 + frow) * 8) = norm_scale8(fz, sc, fwv);
+        }
+        __syncthreads();
+    }
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) {
         bf16x8 af[MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const bf16x8*>(arow[mt] + kt * a_step);
+        for (int mt = 0; mt < MT; ++mt) {
+            if constexpr (FN >= 0) af[mt] = *reinterpret_cast<const bf16x8*>(fn_tile + ((kt0 + kt) * 64 + lane) * 8);
+            else af[mt] = *reinterpret_cast<const bf16x8*>(arow[mt] + kt * a_step);
+        }
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             bf16x8 wv;
@@ -338,17 +379,17 @@ int launch_quantize(const bf16_t* w, uint8_t* wq, float* scale, int N, int K, hi
     return 0;
 }
 
-template <int NB, int MT, int KW, int KT, int EPI, bool W8>
+template <int NB, int MT, int KW, int KT, int EPI, bool W8, int FN = -1>
 static int launch_w(const GemmArgs& a, int nblocks, hipStream_t st, int ksplit) {
     constexpr size_t lds = (size_t)KW * NB * MT * 64 * sizeof(f32x4);
     static bool attr_set = false;
     if (!attr_set) {
-        T3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_stream_kernel<NB, MT, KW, KT, EPI, W8>),
+        T3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_stream_kernel<NB, MT, KW, KT, EPI, W8, FN>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     const int groups = (a.M + MT * 16 - 1) / (MT * 16);
-    T3_LAUNCH((gemm_stream_kernel<NB, MT, KW, KT, EPI, W8>), dim3(nblocks, groups, ksplit), dim3(KW * 64), lds, st, a);
+    T3_LAUNCH((gemm_stream_kernel<NB, MT, KW, KT, EPI, W8, FN>), dim3(nblocks, groups, ksplit), dim3(KW * 64), lds, st, a);
     T3_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -362,6 +403,21 @@ static int launch_one(const GemmArgs& a, int nblocks, hipStream_t st, int ksplit
         T3_REQUIRE(a.wscale == nullptr, "gemm: this shape has no int8 form");
     }
     return launch_w<NB, MT, KW, KT, EPI, false>(a, nblocks, st, ksplit);
+}
+
+// the projection with the residual-add + RMSNorm in its prologue (GemmArgs::fn_*), a.M <= GEMM_FUSED_NORM_ROWS
+template <int EPI>
+static int launch_fused_norm(const GemmArgs& a, int nblocks, hipStream_t st) {
+    T3_REQUIRE(a.M <= GEMM_FUSED_NORM_ROWS && a.K == 1024, "gemm: the norm prologue takes at most 4 rows and K = 1024");
+    T3_REQUIRE(a.fn_res_in && (a.fn_nsplit == 0 || (a.fn_nsplit == GEMM_SLAB_SPLIT && a.fn_slab && a.fn_res_out &&
+                                                    a.fn_res_out != a.fn_res_in)),
+               "gemm: the norm prologue needs the residual rows, and for folded slabs a separate buffer for the new rows");
+    if (a.fn_nsplit == 0) {
+        if (a.wscale) return launch_w<2, 1, 8, 4, EPI, true, 0>(a, nblocks, st, 1);
+        return launch_w<2, 1, 8, 4, EPI, false, 0>(a, nblocks, st, 1);
+    }
+    if (a.wscale) return launch_w<2, 1, 8, 4, EPI, true, GEMM_SLAB_SPLIT>(a, nblocks, st, 1);
+    return launch_w<2, 1, 8, 4, EPI, false, GEMM_SLAB_SPLIT>(a, nblocks, st, 1);
 }
 
 template <int NB, int KW, int KT, int EPI>
@@ -379,6 +435,7 @@ int launch_gemm(int epi, const GemmArgs& a, hipStream_t st) {
     T3_REQUIRE(!(a.a_tiled && a.a_rows), "gemm: a row gather reads row-major activations");
     T3_REQUIRE(!a.c_tiled || epi == EPI_SILU, "gemm: only the SiLU form writes tile-ordered output");
     T3_REQUIRE(a.K == 1024 || a.K == 4096, "gemm: K must be 1024 or 4096");
+    T3_REQUIRE(a.fn_w == nullptr || epi == EPI_SILU || epi == EPI_QKV_ROPE, "gemm: only the SiLU and QKV forms take the norm prologue");
     switch (epi) {
         case EPI_STORE:
             if (a.a_rows) {
@@ -392,10 +449,12 @@ int launch_gemm(int epi, const GemmArgs& a, hipStream_t st) {
             return launch_mt<1, 16, 8, EPI_RESID>(a, a.N / 16, st);
         case EPI_SILU:
             T3_REQUIRE(a.K == 1024 && a.N % 64 == 0, "gemm_silu: K must be 1024, N = 2F with F % 32 == 0");
+            if (a.fn_w) return launch_fused_norm<EPI_SILU>(a, a.N / 32, st);
             return launch_mt<2, 8, 4, EPI_SILU>(a, a.N / 32, st);
         case EPI_QKV_ROPE:
             T3_REQUIRE(a.K == 1024 && a.kv.hd == 64 && a.N == 3 * a.kv.H * 64, "gemm_qkv: needs K=1024, head_dim 64");
             T3_REQUIRE(a.ldc % 4 == 0, "gemm_qkv: ldc must be a multiple of 4");
+            if (a.fn_w) return launch_fused_norm<EPI_QKV_ROPE>(a, a.N / 32, st);
             // only 96 column pairs: above 32 rows, row groups of 32 put twice the workgroups to work, each
             // reading half the activations (the groups of one column pair share an XCD, hence its L2 copy of W)
             if (a.M > 32) return launch_one<2, 2, 8, 4, EPI_QKV_ROPE>(a, a.N / 32, st);

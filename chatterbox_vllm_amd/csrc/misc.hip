@@ -3,12 +3,6 @@
 // per row, 16-byte loads, wave shuffles for the reductions.
 #include "t3_common.h"
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-
 // ------------------------------------------------------------------------------------
 // res = bf16(x + res) (x optional) ; xn = bf16(bf16(res * rsqrt(mean(res^2) + eps)) * w)
 // One workgroup of 128 threads per row, 8 elements per thread per pass.
@@ -71,75 +65,30 @@ __global__ __launch_bounds__(SLAB_NORM_THREADS) void slab_add_rmsnorm_kernel(con
                                                                const bf16_t* __restrict__ w, bf16_t* __restrict__ xn,
                                                                float eps, int xn_tiled) {
     constexpr int d = 1024;
-    constexpr int NT = SLAB_NORM_THREADS, EPT = d / NT, NV = EPT / 4;   // elements per thread, fp32x4 pieces per thread
-    __shared__ float part[NT / 64];
+    __shared__ float part[2];
     const size_t row = blockIdx.x;
-    const int tid = threadIdx.x, c = tid * EPT;
-    float z[EPT], wz[EPT];
-    if constexpr (EPT == 8) {
-        const u32x4 rv = *reinterpret_cast<const u32x4*>(res + row * d + c);
-        const u32x4 wv = *reinterpret_cast<const u32x4*>(w + c);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { z[2 * i] = bf_lo(rv[i]); z[2 * i + 1] = bf_hi(rv[i]); wz[2 * i] = bf_lo(wv[i]); wz[2 * i + 1] = bf_hi(wv[i]); }
-    } else {
-        const u32x2 rv = *reinterpret_cast<const u32x2*>(res + row * d + c);
-        const u32x2 wv = *reinterpret_cast<const u32x2*>(w + c);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) { z[2 * i] = bf_lo(rv[i]); z[2 * i + 1] = bf_hi(rv[i]); wz[2 * i] = bf_lo(wv[i]); wz[2 * i + 1] = bf_hi(wv[i]); }
-    }
+    const int tid = threadIdx.x, c = tid * 8;
+    float z[8];
+    unpack8(*reinterpret_cast<const u32x4*>(res + row * d + c), z);
+    const u32x4 wv = *reinterpret_cast<const u32x4*>(w + c);
     if constexpr (NSPLIT > 0) {
-        const float* sp = slab + row * d + c;
-        f32x4 p[NSPLIT][NV];                               // all partial loads in flight at once
-#pragma unroll
-        for (int s = 0; s < NSPLIT; ++s)
-#pragma unroll
-            for (int v = 0; v < NV; ++v) p[s][v] = *reinterpret_cast<const f32x4*>(sp + s * slab_stride + 4 * v);
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            f32x4 a = p[0][v];
-#pragma unroll
-            for (int s = 1; s < NSPLIT; ++s) a += p[s][v];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) z[4 * v + i] = rbf(rbf(a[i]) + z[4 * v + i]);
-        }
-        if constexpr (EPT == 8) {
-            u32x4 o;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) o[i] = pack_bf2(z[2 * i], z[2 * i + 1]);
-            *reinterpret_cast<u32x4*>(res + row * d + c) = o;
-        } else {
-            const u32x2 o = {pack_bf2(z[0], z[1]), pack_bf2(z[2], z[3])};
-            *reinterpret_cast<u32x2*>(res + row * d + c) = o;
-        }
+        norm_fold8<NSPLIT>(slab + row * d + c, slab_stride, z);
+        *reinterpret_cast<u32x4*>(res + row * d + c) = pack8(z);
     }
-    float ss = 0.f;
-#pragma unroll
-    for (int i = 0; i < EPT; ++i) ss += z[i] * z[i];
-    ss = wave_sum(ss);
+    const float ss = wave_sum(norm_ssq8(z));
     if ((tid & 63) == 0) part[tid >> 6] = ss;
     __syncthreads();
-    float tot = part[0];
-#pragma unroll
-    for (int k = 1; k < NT / 64; ++k) tot += part[k];
-    const float sc = 1.0f / sqrtf(tot / (float)d + eps);
-    if constexpr (EPT == 8) {
-        u32x4 o;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = pack_bf2(rbf(z[2 * i] * sc) * wz[2 * i], rbf(z[2 * i + 1] * sc) * wz[2 * i + 1]);
-        // activation tile order (t3_common.h): this thread's 8 columns are one 16-byte fragment piece
-        const size_t off = xn_tiled ? ((row >> 4) * (d >> 5) + (tid >> 2)) * 512 + ((tid & 3) * 16 + (row & 15)) * 8
-                                    : row * d + c;
-        *reinterpret_cast<u32x4*>(xn + off) = o;
-    } else {
-        const u32x2 o = {pack_bf2(rbf(z[0] * sc) * wz[0], rbf(z[1] * sc) * wz[1]), pack_bf2(rbf(z[2] * sc) * wz[2], rbf(z[3] * sc) * wz[3])};
-        *reinterpret_cast<u32x2*>(xn + row * d + c) = o;
-    }
+    const float sc = norm_rstd(part[0] + part[1], eps);
+    // activation tile order (t3_common.h): this thread's 8 columns are one 16-byte fragment piece
+    const size_t off = xn_tiled ? ((row >> 4) * (d >> 5) + (tid >> 2)) * 512 + ((tid & 3) * 16 + (row & 15)) * 8
+                                : row * d + c;
+    *reinterpret_cast<u32x4*>(xn + off) = norm_scale8(z, sc, wv);
 }
 
 int launch_slab_add_rmsnorm(const float* slab, int nsplit, bf16_t* res, const bf16_t* w, bf16_t* xn, int rows, int d,
                             float eps, hipStream_t st, bool xn_tiled) {
     T3_REQUIRE(rows >= 1 && d == 1024, "slab_add_rmsnorm: d must be 1024");
-    static_assert(SLAB_NORM_THREADS == 128, "the tile-ordered store assumes 8 columns per thread");
+    static_assert(SLAB_NORM_THREADS == 128, "8 columns per thread, two waves per row");
     T3_REQUIRE(nsplit == 0 || (slab != nullptr && nsplit == GEMM_SLAB_SPLIT), "slab_add_rmsnorm: nsplit must be 0 or the split count");
     if (nsplit == 0)
         T3_LAUNCH(slab_add_rmsnorm_kernel<0>, dim3(rows), dim3(SLAB_NORM_THREADS), 0, st, slab, (size_t)rows * d, res, w, xn, eps,

@@ -27,6 +27,67 @@ __device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
     return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
 }
 
+// ---- the residual-add + RMSNorm arithmetic of one thread (8 consecutive columns of a 1024-wide row) ---------
+// Shared by the norm kernel and by the projection kernels that do the norm in their prologue for launches of a few
+// rows: both must produce the same bits, so both run exactly these operations in exactly this order.
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+// z = the thread's 8 residual values; folds the split-K partial sums in: z = bf16(bf16(slab[0] + slab[1] + ...) + z)
+// (loads and sums are separate so that a caller can put other loads between them)
+template <int NSPLIT>
+__device__ __forceinline__ void norm_load8(const float* __restrict__ sp, size_t slab_stride, f32x4 (&p)[NSPLIT > 0 ? NSPLIT : 1][2]) {
+#pragma unroll
+    for (int s = 0; s < NSPLIT; ++s)                       // all partial loads in flight at once
+#pragma unroll
+        for (int v = 0; v < 2; ++v) p[s][v] = *reinterpret_cast<const f32x4*>(sp + s * slab_stride + 4 * v);
+}
+template <int NSPLIT>
+__device__ __forceinline__ void norm_sum8(const f32x4 (&p)[NSPLIT > 0 ? NSPLIT : 1][2], float z[8]) {
+    if constexpr (NSPLIT > 0) {
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            f32x4 a = p[0][v];
+#pragma unroll
+            for (int s = 1; s < NSPLIT; ++s) a += p[s][v];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) z[4 * v + i] = rbf(rbf(a[i]) + z[4 * v + i]);
+        }
+    }
+}
+template <int NSPLIT>
+__device__ __forceinline__ void norm_fold8(const float* __restrict__ sp, size_t slab_stride, float z[8]) {
+    f32x4 p[NSPLIT > 0 ? NSPLIT : 1][2];
+    norm_load8<NSPLIT>(sp, slab_stride, p);
+    norm_sum8<NSPLIT>(p, z);
+}
+__device__ __forceinline__ float norm_ssq8(const float z[8]) {
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ss = fmaf(z[i], z[i], ss);
+    return ss;
+}
+__device__ __forceinline__ float norm_rstd(float sum_sq, float eps) { return 1.0f / sqrtf(sum_sq / 1024.0f + eps); }
+__device__ __forceinline__ u32x4 norm_scale8(const float z[8], float sc, const u32x4 wv) {
+    u32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        o[i] = pack_bf2(rbf(z[2 * i] * sc) * bf_lo(wv[i]), rbf(z[2 * i + 1] * sc) * bf_hi(wv[i]));
+    return o;
+}
+__device__ __forceinline__ void unpack8(const u32x4 v, float z[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { z[2 * i] = bf_lo(v[i]); z[2 * i + 1] = bf_hi(v[i]); }
+}
+__device__ __forceinline__ u32x4 pack8(const float z[8]) {
+    u32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = pack_bf2(z[2 * i], z[2 * i + 1]);
+    return o;
+}
+
 // ---- error plumbing (host) -------------------------------------------------------
 void t3_set_error(const std::string& msg);
 #define T3_HIP_CHECK(expr)                                                                   \
@@ -72,6 +133,7 @@ struct KvView {
 // ---- launchers (all asynchronous on `st`) -------------------------------------------
 enum GemmEpilogue { EPI_STORE = 0, EPI_RESID = 1, EPI_SILU = 2, EPI_QKV_ROPE = 3, EPI_SLAB = 4, EPI_STORE_GATHER = 5 };
 #define GEMM_SLAB_SPLIT 8          // K is cut into 8 block-level ranges in the split-K (slab) form
+#define GEMM_FUSED_NORM_ROWS 4     // launches of at most this many rows can take the residual-add + RMSNorm into the projection
 
 struct GemmArgs {
     const bf16_t* A; int lda;          // activations [M, K]
@@ -91,6 +153,11 @@ struct GemmArgs {
     KvView kv; int layer;
     // EPI_SLAB
     float* slab;                       // [GEMM_SLAB_SPLIT][M][N] fp32 partial sums
+    // Norm in the prologue (EPI_SILU / EPI_QKV_ROPE, K = 1024, M <= GEMM_FUSED_NORM_ROWS): when fn_w is set, A is unused and
+    // the kernel itself computes res' = bf16(bf16(sum of fn_nsplit slabs) + fn_res_in) (fn_nsplit = 0: res' = fn_res_in)
+    // and multiplies with rmsnorm(res') * fn_w, bit for bit what launch_slab_add_rmsnorm would have handed it; workgroup 0
+    // stores res' to fn_res_out (a buffer other than fn_res_in: every workgroup reads fn_res_in)
+    const float* fn_slab; int fn_nsplit; const bf16_t* fn_res_in; bf16_t* fn_res_out; const bf16_t* fn_w; float fn_eps;
 #ifdef T3_GEMM_TIMELINE
     long long* ts;                     // tools/gemm_timeline.hip: [block][wave][8] wall-clock stamps
 #endif

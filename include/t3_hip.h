@@ -229,6 +229,17 @@ typedef struct t3_gemm_desc {
      * of 16; element (r, k) at ((r/16)*(K/32) + k/32)*512 + ((k%32)/8*16 + r%16)*8 + k%8.                    */
     int32_t a_tiled;              /* a_dev is in activation tile order (streaming form only)                  */
     int32_t out_tiled;            /* epilogue 2: h is written in activation tile order (streaming form only)  */
+    /* Residual-add + RMSNorm in the prologue (streaming form, epilogues 2 and 3, K = 1024, M <= 4): when fn_norm_w_dev
+     * is set, a_dev is ignored and the projection reads rmsnorm(res') * fn_norm_w with
+     * res' = bf16(bf16(fn_slab[0] + ... + fn_slab[fn_nsplit-1]) + fn_res_in) (fn_nsplit 0: res' = fn_res_in), the bits
+     * t3_op_slab_add_rmsnorm would have produced; res' is stored to fn_res_out_dev (not the buffer of fn_res_in_dev).
+     * What the engine runs for decode steps of at most 4 rows.                                                    */
+    const float* fn_slab_dev;     /* [fn_nsplit][M][1024] fp32, or NULL                                          */
+    const void* fn_res_in_dev;    /* [M, 1024] bf16                                                              */
+    void* fn_res_out_dev;         /* [M, 1024] bf16 (fn_nsplit > 0)                                              */
+    const void* fn_norm_w_dev;    /* [1024] bf16; NULL = no norm prologue                                        */
+    int32_t fn_nsplit;            /* 0 or t3_op_slab_split()                                                     */
+    float fn_eps;
 } t3_gemm_desc;
 int t3_op_gemm_ex(const t3_gemm_desc* desc, void* stream);
 /* Single-query attention over the paged KV cache: row r attends to positions

@@ -260,6 +260,63 @@ def test_attn_prefill_is_causal_per_sequence(capi):
         assert_bf16_close(out[s0:s0 + L], ref, max_frac=0.05, what=f"attn_prefill len={L}")
 
 
+@pytest.mark.parametrize("int8", [False, True])
+@pytest.mark.parametrize("nsplit_on", [True, False])
+@pytest.mark.parametrize("M", [1, 2, 3, 4])
+def test_norm_in_the_projection_prologue_has_the_bits_of_the_norm_kernel(capi, M, nsplit_on, int8):
+    """Few-row decode form: the projection folds the split-K slabs into the residual rows and normalises them itself.
+    Outputs (h of gate_up, q|k|v and the cache rows of the QKV projection) and the updated residual rows must equal,
+    bit for bit, what the norm kernel followed by the plain projection gives, over several seeds and magnitudes."""
+    H, hd, K, F = 16, 64, 1024, 4096
+    S = capi.t3_op_slab_split()
+    cfg = T3ModelConfig.english()
+    wgu = _rand((2 * F, K), 301, 0.03).to(DEV)
+    wqkv = _rand((3 * H * hd, K), 302, 0.03).to(DEV)
+    if int8:
+        wgu_t, sgu = _quantized(capi, wgu)
+        wqkv_t, sqkv = _quantized(capi, wqkv)
+    else:
+        wgu_t, sgu, wqkv_t, sqkv = repack(capi, wgu), None, repack(capi, wqkv), None
+    rope = W.rope_table(cfg, 1000).to(DEV)
+    for seed, scale in ((310, 1.0), (311, 30.0), (312, 0.01), (313, 4.0)):
+        res = _rand((M, K), seed, scale).to(DEV)
+        slab = (torch.randn(S, M, K, generator=torch.Generator().manual_seed(seed + 50)) * scale * 0.3).to(DEV)
+        nw = (1.0 + 0.1 * torch.randn(K, generator=torch.Generator().manual_seed(seed + 60))).to(torch.bfloat16).to(DEV)
+        ns = S if nsplit_on else 0
+        # the two-kernel way: norm kernel (tile-ordered xn), then the projections
+        res_a = res.clone()
+        xn = torch.zeros(16 * K, dtype=torch.bfloat16, device=DEV)
+        call(capi, "t3_op_slab_add_rmsnorm_tiled", p(slab), ns, p(res_a), p(nw), p(xn), M, K, 1e-5, None)
+        h_a = torch.zeros(M, F, dtype=torch.bfloat16, device=DEV)
+        d = _desc(a_dev=xn, w_dev=wgu_t, w_scale_dev=sgu, out_dev=h_a, M=M, N=2 * F, K=K, epilogue=2, a_tiled=1)
+        call(capi, "t3_op_gemm_ex", C.byref(d), None)
+        pool_a, bt, layer_stride = _kv_setup(M, 16, 1, seed=seed)
+        pos = torch.randperm(1000, generator=torch.Generator().manual_seed(seed + 70))[:M].to(torch.int32).to(DEV)
+        std, btd = torch.arange(M, dtype=torch.int32, device=DEV), bt.to(DEV)
+        qkv_a = torch.zeros(M, 3 * H * hd, dtype=torch.bfloat16, device=DEV)
+        common = dict(M=M, N=3 * H * hd, K=K, epilogue=3, H=H, hd=hd, layer=0, max_pages=16, rope_dev=rope, pos_dev=pos,
+                      stream_dev=std, layer_stride_elems=layer_stride, block_table_dev=btd, w_dev=wqkv_t, w_scale_dev=sqkv)
+        d = _desc(a_dev=xn, out_dev=qkv_a, kv_pool_dev=pool_a, a_tiled=1, **common)
+        call(capi, "t3_op_gemm_ex", C.byref(d), None)
+        # the one-kernel way
+        res_b = torch.zeros_like(res)
+        fn = dict(fn_slab_dev=slab if ns else None, fn_res_in_dev=res, fn_res_out_dev=res_b if ns else None, fn_norm_w_dev=nw,
+                  fn_nsplit=ns, fn_eps=1e-5)
+        h_b = torch.zeros_like(h_a)
+        d = _desc(w_dev=wgu_t, w_scale_dev=sgu, out_dev=h_b, M=M, N=2 * F, K=K, epilogue=2, **fn)
+        call(capi, "t3_op_gemm_ex", C.byref(d), None)
+        pool_b = torch.zeros_like(pool_a)
+        qkv_b = torch.zeros_like(qkv_a)
+        d = _desc(out_dev=qkv_b, kv_pool_dev=pool_b, **common, **fn)
+        call(capi, "t3_op_gemm_ex", C.byref(d), None)
+        torch.cuda.synchronize()
+        assert torch.equal(h_a, h_b), f"gate_up seed {seed}"
+        assert torch.equal(qkv_a, qkv_b) and torch.equal(pool_a, pool_b), f"qkv seed {seed}"
+        if ns:
+            assert torch.equal(res_a, res_b), f"residual rows seed {seed}"
+        assert h_a.float().abs().sum() > 0 and qkv_a.float().abs().sum() > 0
+
+
 def test_attn_decode_with_shared_prefix_page_has_the_bits_of_private_copies(capi):
     """Positions [0, 34) of some rows live in one shared page; the row's own page 0 holds garbage there."""
     H, hd, NP = 16, 64, 34

@@ -168,3 +168,32 @@ def test_postprocess_ids():
     assert postprocess_ids([1005, 1006, 1007, 1008, S, 1009]) == [5, 6]
     assert postprocess_ids([1005, 7561, 1006, 9000]) == [6]          # after SOS, drop ids >= 6561
     assert postprocess_ids([1001, S]) == []
+
+
+def test_oracle_reproduces_its_committed_golden_outputs():
+    """tests/golden/oracle_golden.json (made by make_oracle_golden.py) pins what the oracle computes: ids of every
+    decisive step and the logit slices, for the 2-layer case under all three stream semantics.  (A step counts as
+    decisive when its top-2 margin exceeds the bf16 tolerance of the engine tests; fp32 summation order may differ
+    between CPUs.)"""
+    import json, os
+    from chatterbox_vllm_amd.config import T3ModelConfig
+    from chatterbox_vllm_amd import weights as W
+    from oracle.t3_oracle import T3Oracle, SamplingSpec, build_prompt_ids
+    with open(os.path.join(os.path.dirname(__file__), "golden", "oracle_golden.json")) as f:
+        gold = json.load(f)["micro"]
+    sd = W.synthetic_state_dict(T3ModelConfig.english(n_layers=gold["n_layers"]))
+    tol = (1 + 2 * gold["cfg_scale"]) * 2 ** -5
+    for req in gold["requests"]:
+        assert build_prompt_ids(req["text_ids"]) == req["prompt_ids"]
+        for mode, g in req["modes"].items():
+            paired = mode != "single_stream"
+            o = T3Oracle(sd, n_layers=gold["n_layers"], cfg_scale=gold["cfg_scale"] if paired else 0.0,
+                         uncond_attends=mode != "paired_uncond_no_attention")
+            r = o.generate_one(req["text_ids"], W.synthetic_cond_emb(req["voice"]), SamplingSpec(max_tokens=gold["max_tokens"]),
+                               max_model_len=gold["max_model_len"], paired=paired, forced=g["token_ids"], return_logits=True)
+            for t, (tok, margin) in enumerate(zip(g["token_ids"], g["margins"])):
+                got = r["logits"][t][1000:1008]
+                want = torch.tensor(g["logits_1000_1008"][t])
+                assert (got - want).abs().max().item() <= tol, f"{mode} step {t}"
+                if margin > 2 * tol:
+                    assert r["picks"][t] == tok, f"{mode} step {t}: decisive step changed its pick"

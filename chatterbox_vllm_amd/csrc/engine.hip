@@ -1143,6 +1143,7 @@ extern "C" int t3_engine_step(t3_engine* e, int64_t* out_req_ids, int32_t* out_t
         if (!report) {
             const hipError_t qs = hipEventQuery(e->pjob_done);
             if (qs != hipSuccess && qs != hipErrorNotReady) T3_HIP_CHECK(qs);
+            if (qs == hipErrorNotReady) (void)hipGetLastError();   // "not ready" is an answer, not an error to find after a launch
             report = qs == hipSuccess;
             if (!report) {                                    // nothing decoding and nothing in flight: wait for it
                 bool busy = e->inflight.valid;

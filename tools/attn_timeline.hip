@@ -35,6 +35,19 @@ int main(int argc, char** argv) {
     int64_t ctx_total = 0;
     for (int r = 0; r < rows; ++r) { rs[r] = r; rc[r] = 100 + (int)(rnd() % 690); }
     if (sorted) std::sort(rc.begin(), rc.end(), [](int a, int b) { return a > b; });
+    if (sorted == 2) {                                     // longest, shortest, 2nd longest, 2nd shortest, ...
+        std::vector<int32_t> z;
+        for (int i = 0, j = rows - 1; i <= j; ++i, --j) { z.push_back(rc[i]); if (i != j) z.push_back(rc[j]); }
+        rc = z;
+    }
+    if (sorted == 3) {                                     // long rows first, in groups of 8 with 8 short rows in between
+        std::vector<int32_t> z;
+        for (int g = 0; g < rows / 16; ++g) {
+            for (int k = 0; k < 8; ++k) z.push_back(rc[g * 8 + k]);
+            for (int k = 0; k < 8; ++k) z.push_back(rc[rows - 1 - g * 8 - k]);
+        }
+        if ((int)z.size() == rows) rc = z;
+    }
     for (int r = 0; r < rows; ++r) ctx_total += rc[r];
     int32_t *d_bt, *d_rs, *d_rc; bf16_t *qkv, *out; long long* ts;
     CK(hipMalloc((void**)&d_bt, bt.size() * 4)); CK(hipMemcpy(d_bt, bt.data(), bt.size() * 4, hipMemcpyHostToDevice));

@@ -173,3 +173,21 @@ def test_sharding_world2_gloo():
         assert ok_bcast and ok_gen
         assert ragged == [[0], [], [5, 6, 7]]
     assert res[0][4] == [0, 2, 4, 6] and res[1][4] == [1, 3, 5]
+
+
+def test_benchmark_job_builder_follows_the_reference_histogram(text_fx):
+    """bench.py's synthetic job: 154 requests with the text-id counts of the reference's benchmark input, output
+    lengths proportional to them with the README-implied mean, everything inside max_model_len; deterministic."""
+    import bench
+    job = bench.build_job(seed=7)
+    lens = text_fx["benchmark_text_1"]["text_id_counts"]
+    assert [len(t) for t, _, _ in job] == [max(3, n) for n in lens] and len(job) == 154
+    assert all(t[0] == 255 and t[-1] == 0 and all(0 <= i < 704 for i in t) for t, _, _ in job)
+    assert all(16 <= o and 34 + len(t) + 1 + o <= bench.MAX_MODEL_LEN for t, o, _ in job)
+    mean_out = sum(o for _, o, _ in job) / len(job)
+    assert abs(mean_out - bench.MEAN_OUT) < 25
+    assert bench.build_job(seed=7) == job and bench.build_job(seed=8) != job
+    single = bench.build_job(seed=7, workload="single")
+    assert len(single) == 1 and 34 + len(single[0][0]) + 1 + single[0][1] == bench.MAX_MODEL_LEN
+    mtl = bench.build_job(seed=7, workload="multilingual")
+    assert len(mtl) == 128 and {v for _, _, v in mtl} == {0, 1, 2, 3} and {t[0] for t, _, _ in mtl} == {634, 725}

@@ -156,6 +156,8 @@ def main():
                          "token ids are the same under both")
     ap.add_argument("--uncond-no-attention", action="store_true",
                     help="engine mode cfg_paired=2: the uncond row has no attention and no KV (not the benchmark)")
+    ap.add_argument("--max-prefill-rows", type=int, default=2048,
+                    help="prompt positions (per stream) one prefill job may hold; vLLM's counterpart is max_num_batched_tokens")
     ap.add_argument("--no-prefix-sharing", action="store_true",
                     help="every stream prefills and keeps its own copy of the 34 conditioning positions (same ids)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
@@ -195,7 +197,7 @@ def main():
     conds = [W.synthetic_cond_emb(v) for v in range(4)]
     job = build_job(seed=7 + rank, n_requests=args.requests, workload=args.workload, repeat=args.repeat_job)
     eng = T3Engine(cfg, sd, max_model_len=MAX_MODEL_LEN, max_num_seqs=conc, cfg_scale=CFG_SCALE,
-                   cfg_paired=paired, device=local_rank, max_prefill_rows=2048,
+                   cfg_paired=paired, device=local_rank, max_prefill_rows=args.max_prefill_rows,
                    quantization=None if args.quantization == "none" else args.quantization,
                    scheduling_policy=args.policy, uncond_attends=not args.uncond_no_attention,
                    prefix_sharing=not args.no_prefix_sharing)

@@ -246,17 +246,33 @@ class T3Engine:
             for rid in added:
                 self.abort(rid)
             raise
-        while self.has_unfinished():
-            for rid, tok, fin in self.step():
-                ro = by_id.get(rid)
-                if ro is None:
-                    continue
-                ro.outputs[0].token_ids.append(tok)
-                if fin is not None:
-                    ro.outputs[0].finish_reason = fin
-                    ro.finished = True
-            if on_step is not None:
-                on_step(self)
+        try:
+            while self.has_unfinished():
+                for rid, tok, fin in self.step():
+                    ro = by_id.get(rid)
+                    if ro is None:
+                        continue
+                    ro.outputs[0].token_ids.append(tok)
+                    if fin is not None:
+                        ro.outputs[0].finish_reason = fin
+                        ro.finished = True
+                if on_step is not None:
+                    on_step(self)
+        except BaseException:
+            # an interrupted call must not leave its requests behind for the next one: abort them and let the
+            # steps in flight drain (their tokens are dropped)
+            for rid, ro in by_id.items():
+                if not ro.finished:
+                    try:
+                        self.abort(rid)
+                    except Exception:
+                        pass
+            try:
+                while self.has_unfinished():
+                    self.step()
+            except Exception:
+                pass
+            raise
         return outs
 
     # ---- life cycle -------------------------------------------------------------------

@@ -223,6 +223,27 @@ def test_shared_prefix_gives_the_bits_of_private_prefixes(small, paired, uncond_
     assert rows_s == 34 + streams * (P1 + P2 - 68) + ghosts
 
 
+def test_an_interrupted_generate_call_leaves_no_requests_behind(small):
+    cfg, sd = small
+    eng = T3Engine(cfg, sd, max_model_len=128, max_num_seqs=2, cfg_scale=0.5)
+    items = _items([_text(5, 1), _text(9, 2), _text(4, 3)], [0, 1, 0])
+    sp = SamplingParams(temperature=0.0, repetition_penalty=2.0, max_tokens=20, stop_token_ids=[STOP])
+    want = [o.outputs[0].token_ids for o in eng.generate(items, sp)]
+    calls = 0
+
+    def boom(_):
+        nonlocal calls
+        calls += 1
+        if calls == 6:
+            raise KeyboardInterrupt
+
+    with pytest.raises(KeyboardInterrupt):
+        eng.generate(items, sp, on_step=boom)
+    assert not eng.has_unfinished()
+    assert [o.outputs[0].token_ids for o in eng.generate(items, sp)] == want
+    eng.shutdown()
+
+
 def test_stop_and_length_rules(small):
     cfg, sd = small
     text = _text(6, 7)

@@ -111,20 +111,20 @@ def run_job(eng: T3Engine, job, conds, stats=None):
 
 def cpu_baseline(cfg, sd, job, conds, paired=True):
     """The oracle on a bounded slice: 8 requests of the job (the 8 shortest texts), CFG-paired,
-    prefill + 64 greedy tokens each, batched decode steps (10-30 s of CPU work)."""
+    prefill + 96 greedy tokens each, batched decode steps (10-30 s of CPU work)."""
     from oracle.t3_oracle import T3Oracle
     torch.set_num_threads(max(1, min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))))
     o = T3Oracle(sd, n_layers=cfg.n_layers, cfg_scale=CFG_SCALE)
     sub = sorted(job, key=lambda t: len(t[0]))[:8]
     reqs = [(t, conds[v]) for t, _, v in sub]
     t0 = time.time()
-    out = o.generate_batch(reqs, [64] * len(reqs), paired=paired)
+    out = o.generate_batch(reqs, [96] * len(reqs), paired=paired)
     dt = time.time() - t0
     ntok = sum(len(x) for x in out)
     return {"value": round(ntok / dt, 3), "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{len(reqs)} shortest requests of the job (text ids {[len(t) for t, _, _ in sub]}), "
                       f"{'CFG-paired' if paired else 'single stream'}, "
-                      f"prefill + 64 greedy tokens each, batched decode, {dt:.1f} s of CPU time"}, out, sub
+                      f"prefill + 96 greedy tokens each, batched decode, {dt:.1f} s of CPU time"}, out, sub
 
 
 def _pmc_traffic(kernel_class):

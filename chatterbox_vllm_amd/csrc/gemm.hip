@@ -75,7 +75,8 @@ __global__ __launch_bounds__(KW * 64) void gemm_stream_kernel(GemmArgs a) {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) nbi[nb] = b * NB + nb;
     } else {
-        nbi[0] = b;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) nbi[nb] = b * NB + nb;
     }
 
     f32x4 acc[NB][MT];
@@ -239,25 +240,28 @@ __global__ __launch_bounds__(KW * 64) void gemm_stream_kernel(GemmArgs a) {
             for (int nb = 0; nb < NB; ++nb)
                 *reinterpret_cast<f32x4*>(a.slab + ((size_t)blockIdx.z * a.M + r) * a.N + nbi[nb] * 16 + nl) = s[nb];
         } else if constexpr (EPI == EPI_STORE || EPI == EPI_STORE_GATHER || EPI == EPI_RESID) {
-            const int n = nbi[0] * 16 + nl;
-            bf16_t* cp = a.C + (size_t)r * a.ldc + n;
-            float v[4] = {rbf(s[0][0]), rbf(s[0][1]), rbf(s[0][2]), rbf(s[0][3])};
-            const bool vec = ((a.ldc & 3) == 0) && (n + 3 < a.n_valid);
-            if constexpr (EPI == EPI_RESID) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const int n = nbi[nb] * 16 + nl;
+                bf16_t* cp = a.C + (size_t)r * a.ldc + n;
+                float v[4] = {rbf(s[nb][0]), rbf(s[nb][1]), rbf(s[nb][2]), rbf(s[nb][3])};
+                const bool vec = ((a.ldc & 3) == 0) && (n + 3 < a.n_valid);
+                if constexpr (EPI == EPI_RESID) {
+                    if (vec) {
+                        u32x2 o = *reinterpret_cast<const u32x2*>(cp);
+                        v[0] += bf_lo(o[0]); v[1] += bf_hi(o[0]); v[2] += bf_lo(o[1]); v[3] += bf_hi(o[1]);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) if (n + i < a.n_valid) v[i] += bf2f(cp[i]);
+                    }
+                }
                 if (vec) {
-                    u32x2 o = *reinterpret_cast<const u32x2*>(cp);
-                    v[0] += bf_lo(o[0]); v[1] += bf_hi(o[0]); v[2] += bf_lo(o[1]); v[3] += bf_hi(o[1]);
+                    u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+                    *reinterpret_cast<u32x2*>(cp) = o;
                 } else {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) if (n + i < a.n_valid) v[i] += bf2f(cp[i]);
+                    for (int i = 0; i < 4; ++i) if (n + i < a.n_valid) cp[i] = f2bf(v[i]);
                 }
-            }
-            if (vec) {
-                u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
-                *reinterpret_cast<u32x2*>(cp) = o;
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) if (n + i < a.n_valid) cp[i] = f2bf(v[i]);
             }
         } else if constexpr (EPI == EPI_SILU) {
             const int F = a.N >> 1;
@@ -442,6 +446,10 @@ int launch_gemm(int epi, const GemmArgs& a, hipStream_t st) {
                 T3_REQUIRE(a.K == 1024, "gemm: row gather is built for K = 1024");
                 return launch_mt<1, 8, 4, EPI_STORE_GATHER>(a, a.N / 16, st);
             }
+            // many columns (the speech head: 513 column blocks): three blocks per workgroup put the launch into one
+            // generation of workgroups; the per-element accumulation order does not depend on the grouping
+            if (a.K == 1024 && a.N % 48 == 0 && a.N >= 4096 && a.n_valid == a.N && a.M <= 64)   // MT = 8 would not fit the LDS reduction
+                return launch_mt<3, 8, 4, EPI_STORE>(a, a.N / 48, st);
             if (a.K == 1024) return launch_mt<1, 8, 4, EPI_STORE>(a, a.N / 16, st);
             return launch_mt<1, 16, 8, EPI_STORE>(a, a.N / 16, st);
         case EPI_RESID:

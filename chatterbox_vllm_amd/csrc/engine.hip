@@ -197,11 +197,14 @@ struct t3_engine {
     float* dbg_logits = nullptr;                        // [max_num_seqs][vocab+1000] when enabled
     bool keep_logits = false;
 
-    // per-step metadata: one pinned block, one H2D copy per phase
+    // per-step metadata: one pinned block, one H2D copy per phase.  The sampled ids travel the other way without a copy:
+    // the sampler stores them straight into pinned host memory (out_tokens / out_tokens_dev are the two addresses of it),
+    // which the host reads after the step's event.
     struct Meta {
-        Pinned<int32_t> i32; Pinned<float> f32; Pinned<uint64_t> u64;
+        Pinned<uint8_t> blk;
+        int32_t* out_tokens_dev = nullptr;
         int32_t *row_stream, *row_pos, *row_ctx, *row_pfx, *ekind, *eidx, *eaux, *row_c, *row_u, *slot, *step, *a_rows,
-                *seq_start, *seq_pfx, *tiles, *prompt_ids, *out_tokens;     // host views
+                *seq_start, *seq_pfx, *tiles, *prompt_ids, *out_tokens = nullptr;     // host views (out_tokens: its own pinned buffer)
         float *rep, *temp, *top_p, *min_p;
         uint64_t* seed;
         size_t rows_cap = 0, req_cap = 0;
@@ -270,27 +273,28 @@ int meta_alloc(t3_engine::Meta& m, size_t rows, size_t reqs, size_t prompt_ids) 
     // sequences of a prefill step: up to two streams per request plus one per voice built in the step
     const size_t seqs = 3 * reqs + 2, tiles = rows / 32 + 5 * reqs + 64;
     const size_t ni = rows * 7 + reqs * 5 + reqs * 2 /*a_rows*/ + 2 * seqs + 2 * tiles + prompt_ids + 64;
-    if (m.i32.alloc(ni)) return 1;
-    if (m.f32.alloc(reqs * 4 + 16)) return 1;
-    if (m.u64.alloc(reqs + 4)) return 1;
-    int32_t* p = m.i32.h;
+    const size_t nu = reqs + 4, nf = reqs * 4 + 16;
+    if (m.blk.alloc(sizeof(uint64_t) * nu + sizeof(float) * nf + sizeof(int32_t) * ni)) return 1;
+    m.seed = reinterpret_cast<uint64_t*>(m.blk.h);
+    float* f = reinterpret_cast<float*>(m.seed + nu);
+    int32_t* p = reinterpret_cast<int32_t*>(f + nf);
+    T3_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&m.out_tokens), sizeof(int32_t) * reqs, hipHostMallocMapped));
+    T3_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&m.out_tokens_dev), m.out_tokens, 0));
+    std::memset(m.out_tokens, 0, sizeof(int32_t) * reqs);
     m.row_stream = carve(p, rows); m.row_pos = carve(p, rows); m.row_ctx = carve(p, rows); m.row_pfx = carve(p, rows);
     m.ekind = carve(p, rows); m.eidx = carve(p, rows); m.eaux = carve(p, rows);
     m.row_c = carve(p, reqs); m.row_u = carve(p, reqs); m.slot = carve(p, reqs); m.step = carve(p, reqs);
-    m.out_tokens = carve(p, reqs);
     m.a_rows = carve(p, 2 * reqs); m.seq_start = carve(p, seqs); m.seq_pfx = carve(p, seqs); m.tiles = carve(p, 2 * tiles);
     m.prompt_ids = carve(p, prompt_ids);
-    float* f = m.f32.h;
     m.rep = carve(f, reqs); m.temp = carve(f, reqs); m.top_p = carve(f, reqs); m.min_p = carve(f, reqs);
-    m.seed = m.u64.h;
     return 0;
 }
-template <typename T> T* dev_of(const Pinned<T>& p, const T* host_view) { return p.d + (host_view - p.h); }
+template <typename T> T* dev_of(const t3_engine::Meta& m, const T* host_view) {
+    return reinterpret_cast<T*>(m.blk.d + (reinterpret_cast<const uint8_t*>(host_view) - m.blk.h));
+}
 
 int upload(t3_engine* e, t3_engine::Meta& m) {
-    T3_HIP_CHECK(hipMemcpyAsync(m.i32.d, m.i32.h, sizeof(int32_t) * m.i32.n, hipMemcpyHostToDevice, e->cur));
-    T3_HIP_CHECK(hipMemcpyAsync(m.f32.d, m.f32.h, sizeof(float) * m.f32.n, hipMemcpyHostToDevice, e->cur));
-    T3_HIP_CHECK(hipMemcpyAsync(m.u64.d, m.u64.h, sizeof(uint64_t) * m.u64.n, hipMemcpyHostToDevice, e->cur));
+    T3_HIP_CHECK(hipMemcpyAsync(m.blk.d, m.blk.h, m.blk.n, hipMemcpyHostToDevice, e->cur));
     return 0;
 }
 
@@ -421,13 +425,13 @@ int run_head_and_sample(t3_engine* e, t3_engine::Meta& m, int head_rows, const i
     T3_RUN(e, K_HEAD, -1, 2LL * e->head_n * c.d_model, launch_gemm(EPI_STORE, g, e->cur));
     SampleArgs s{};
     s.logits = e->b->logits; s.ldl = e->head_n; s.vocab = c.speech_vocab;
-    s.row_c = dev_of(m.i32, m.row_c); s.row_u = dev_of(m.i32, m.row_u); s.slot = dev_of(m.i32, m.slot);
+    s.row_c = dev_of(m, m.row_c); s.row_u = dev_of(m, m.row_u); s.slot = dev_of(m, m.slot);
     s.n = n_req; s.cfg_scale = c.cfg_scale;
-    s.rep_penalty = dev_of(m.f32, m.rep); s.temperature = dev_of(m.f32, m.temp);
-    s.top_p = dev_of(m.f32, m.top_p); s.min_p = dev_of(m.f32, m.min_p);
-    s.seed = m.u64.d; s.step = dev_of(m.i32, m.step);
+    s.rep_penalty = dev_of(m, m.rep); s.temperature = dev_of(m, m.temp);
+    s.top_p = dev_of(m, m.top_p); s.min_p = dev_of(m, m.min_p);
+    s.seed = dev_of(m, m.seed); s.step = dev_of(m, m.step);
     s.seen = e->seen; s.seen_stride = kSeenStride; s.last_token = e->last_token;
-    s.out_tokens = dev_of(m.i32, m.out_tokens);
+    s.out_tokens = m.out_tokens_dev;
     s.out_logits = e->keep_logits ? e->dbg_logits : nullptr;
     T3_RUN(e, K_SAMPLE, -1, 4LL * n_req * c.speech_vocab, launch_sample(s, e->cur));
     return 0;
@@ -608,22 +612,22 @@ int run_prefill(t3_engine* e, const std::vector<Request*>& reqs) {
     for (int i = 0; i < n; ++i) {
         const int len = reqs[i]->prompt_len;
         T3_RUN(e, K_SEEN, -1, (int64_t)kSeenStride, launch_seen_init(e->seen + (size_t)reqs[i]->slot * kSeenStride, kSeenStride,
-                                                     dev_of(m.i32, m.prompt_ids) + pid, len, e->cur));
+                                                     dev_of(m, m.prompt_ids) + pid, len, e->cur));
         pid += len;
     }
     EmbedArgs ea{};
     ea.out = e->b->res; ea.d = c.d_model; ea.rows = rows;
-    ea.kind = dev_of(m.i32, m.ekind); ea.idx = dev_of(m.i32, m.eidx); ea.aux = dev_of(m.i32, m.eaux);
+    ea.kind = dev_of(m, m.ekind); ea.idx = dev_of(m, m.eidx); ea.aux = dev_of(m, m.eaux);
     ea.cond = e->cond_buf; ea.text_emb = e->text_emb; ea.text_pos = e->text_pos;
     ea.speech_emb = e->speech_emb; ea.speech_pos = e->speech_pos; ea.last_token = e->last_token; ea.sos_id = kSOS;
     T3_RUN(e, K_EMBED, -1, 2LL * rows * c.d_model, launch_embed(ea, e->cur));
     if (rows > first_ghost)
         T3_HIP_CHECK(hipMemsetAsync(e->b->att + (size_t)first_ghost * c.d_model, 0,
                                     sizeof(bf16_t) * (size_t)(rows - first_ghost) * c.d_model, e->cur));
-    if (run_layers(e, rows, dev_of(m.i32, m.row_pos), dev_of(m.i32, m.row_stream), dev_of(m.i32, m.row_ctx), true,
-                   dev_of(m.i32, m.seq_start), dev_of(m.i32, m.tiles), ntiles,
-                   share ? dev_of(m.i32, m.seq_pfx) : nullptr)) return 1;
-    if (run_head_and_sample(e, m, n * S, dev_of(m.i32, m.a_rows), n)) return 1;
+    if (run_layers(e, rows, dev_of(m, m.row_pos), dev_of(m, m.row_stream), dev_of(m, m.row_ctx), true,
+                   dev_of(m, m.seq_start), dev_of(m, m.tiles), ntiles,
+                   share ? dev_of(m, m.seq_pfx) : nullptr)) return 1;
+    if (run_head_and_sample(e, m, n * S, dev_of(m, m.a_rows), n)) return 1;
     e->stats.prefill_requests = n;
     e->stats.prefill_rows = rows;
     e->cur = e->stream;
@@ -637,12 +641,12 @@ int enqueue_decode(t3_engine* e, t3_engine::Meta& m, int B) {
     const int rows = B * e->rows_per_req;
     EmbedArgs ea{};
     ea.out = e->b->res; ea.d = c.d_model; ea.rows = rows;
-    ea.kind = dev_of(m.i32, m.ekind); ea.idx = dev_of(m.i32, m.eidx); ea.aux = dev_of(m.i32, m.eaux);
+    ea.kind = dev_of(m, m.ekind); ea.idx = dev_of(m, m.eidx); ea.aux = dev_of(m, m.eaux);
     ea.cond = e->cond_buf; ea.text_emb = e->text_emb; ea.text_pos = e->text_pos;
     ea.speech_emb = e->speech_emb; ea.speech_pos = e->speech_pos; ea.last_token = e->last_token; ea.sos_id = kSOS;
     T3_RUN(e, K_EMBED, -1, 2LL * rows * c.d_model, launch_embed(ea, e->cur));
-    if (run_layers(e, rows, dev_of(m.i32, m.row_pos), dev_of(m.i32, m.row_stream), dev_of(m.i32, m.row_ctx), false,
-                   nullptr, nullptr, 0, e->share_prefix ? dev_of(m.i32, m.row_pfx) : nullptr)) return 1;
+    if (run_layers(e, rows, dev_of(m, m.row_pos), dev_of(m, m.row_stream), dev_of(m, m.row_ctx), false,
+                   nullptr, nullptr, 0, e->share_prefix ? dev_of(m, m.row_pfx) : nullptr)) return 1;
     return run_head_and_sample(e, m, rows, nullptr, B);
 }
 
@@ -931,7 +935,10 @@ extern "C" int t3_engine_destroy(t3_engine* e) {
 
     }
     e->block_table.release();
-    for (auto* m : {&e->dm[0], &e->dm[1], &e->pm[0], &e->pm[1]}) { m->i32.release(); m->f32.release(); m->u64.release(); }
+    for (auto* m : {&e->dm[0], &e->dm[1], &e->pm[0], &e->pm[1]}) {
+        m->blk.release();
+        if (m->out_tokens) (void)hipHostFree(m->out_tokens);
+    }
     for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
     if (e->pjob_done) (void)hipEventDestroy(e->pjob_done);
     for (auto& ev : e->kpool) (void)hipEventDestroy(ev);
@@ -1186,8 +1193,6 @@ extern "C" int t3_engine_step(t3_engine* e, int64_t* out_req_ids, int32_t* out_t
         if (e->timing) T3_HIP_CHECK(hipEventRecord(e->ev[0], e->stream));
         if (run_prefill(e, admitted)) return 1;
         if (e->timing) T3_HIP_CHECK(hipEventRecord(e->ev[1], e->stream));
-        T3_HIP_CHECK(hipMemcpyAsync(e->pm[q].out_tokens, dev_of(e->pm[q].i32, e->pm[q].out_tokens),
-                                    sizeof(int32_t) * admitted.size(), hipMemcpyDeviceToHost, e->pstream));
         for (Request* r : admitted) r->n_launched = 1;
         if (overlap) {                                     // a job of its own: reported by a later call, see above
             T3_HIP_CHECK(hipEventRecord(e->pjob_done, e->pstream));
@@ -1202,8 +1207,6 @@ extern "C" int t3_engine_step(t3_engine* e, int64_t* out_req_ids, int32_t* out_t
         if (e->timing) T3_HIP_CHECK(hipEventRecord(e->ev[2], e->stream));
         if (run_decode(e, running)) return 1;
         if (e->timing) T3_HIP_CHECK(hipEventRecord(e->ev[3], e->stream));
-        T3_HIP_CHECK(hipMemcpyAsync(e->dm[q].out_tokens, dev_of(e->dm[q].i32, e->dm[q].out_tokens),
-                                    sizeof(int32_t) * running.size(), hipMemcpyDeviceToHost, e->stream));
         for (Request* r : running) r->n_launched++;
     }
     const bool launched = !admitted.empty() || !running.empty();

@@ -278,7 +278,8 @@ int meta_alloc(t3_engine::Meta& m, size_t rows, size_t reqs, size_t prompt_ids) 
     m.seed = reinterpret_cast<uint64_t*>(m.blk.h);
     float* f = reinterpret_cast<float*>(m.seed + nu);
     int32_t* p = reinterpret_cast<int32_t*>(f + nf);
-    T3_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&m.out_tokens), sizeof(int32_t) * reqs, hipHostMallocMapped));
+    T3_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&m.out_tokens), sizeof(int32_t) * reqs,
+                           hipHostMallocMapped | hipHostMallocCoherent));   // fine-grained: device stores reach the host without a cache flush
     T3_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&m.out_tokens_dev), m.out_tokens, 0));
     std::memset(m.out_tokens, 0, sizeof(int32_t) * reqs);
     m.row_stream = carve(p, rows); m.row_pos = carve(p, rows); m.row_ctx = carve(p, rows); m.row_pfx = carve(p, rows);

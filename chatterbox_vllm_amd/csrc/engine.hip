@@ -352,8 +352,10 @@ int dmalloc(bf16_t** p, size_t elems) { T3_HIP_CHECK(hipMalloc(reinterpret_cast<
 
 // ---- the layer stack over `rows` rows whose embeddings are already in e->b->res ----------
 // d_pfx: the shared-prefix page per decode row / per prompt sequence (nullptr without prefix sharing)
+// d_emb_slot (decode steps of more than GEMM_FUSED_NORM_ROWS rows): the first norm fetches the rows' token embeddings itself
 int run_layers(t3_engine* e, int rows, const int32_t* d_pos, const int32_t* d_stream, const int32_t* d_ctx,
-               bool prefill, const int32_t* d_seq_start, const int32_t* d_tiles, int ntiles, const int32_t* d_pfx) {
+               bool prefill, const int32_t* d_seq_start, const int32_t* d_tiles, int ntiles, const int32_t* d_pfx,
+               const int32_t* d_emb_slot = nullptr) {
     const t3_config& c = e->cfg;
     const int D = c.d_model, F = c.d_ff, H = c.n_heads, hd = c.head_dim;
     hipStream_t st = e->cur;
@@ -375,7 +377,9 @@ int run_layers(t3_engine* e, int rows, const int32_t* d_pos, const int32_t* d_st
         // a row's bits never depend on what shares its launch.
         if (!fuse)
             T3_RUN(e, K_NORM, li, 4LL * rows * D, launch_slab_add_rmsnorm(e->b->slab, li > 0 ? GEMM_SLAB_SPLIT : 0, res, L.ln1,
-                                                                          e->b->xn, rows, D, c.rms_eps, st, tiled));
+                                                                          e->b->xn, rows, D, c.rms_eps, st, tiled,
+                                                                          li == 0 && d_emb_slot ? e->speech_emb : nullptr,
+                                                                          d_emb_slot, e->last_token));
         GemmArgs g{};
         if (fuse) {
             g.fn_w = L.ln1; g.fn_eps = c.rms_eps; g.fn_res_in = res; g.fn_nsplit = li > 0 ? GEMM_SLAB_SPLIT : 0;
@@ -645,9 +649,13 @@ int enqueue_decode(t3_engine* e, t3_engine::Meta& m, int B) {
     ea.kind = dev_of(m, m.ekind); ea.idx = dev_of(m, m.eidx); ea.aux = dev_of(m, m.eaux);
     ea.cond = e->cond_buf; ea.text_emb = e->text_emb; ea.text_pos = e->text_pos;
     ea.speech_emb = e->speech_emb; ea.speech_pos = e->speech_pos; ea.last_token = e->last_token; ea.sos_id = kSOS;
-    T3_RUN(e, K_EMBED, -1, 2LL * rows * c.d_model, launch_embed(ea, e->cur));
+    // every decode row is the embedding of its request's last token (kind 4, idx = slot): above the few-row form the
+    // first norm gathers it itself
+    const bool gather_in_norm = !(e->fused_norm && rows <= GEMM_FUSED_NORM_ROWS);
+    if (!gather_in_norm) T3_RUN(e, K_EMBED, -1, 2LL * rows * c.d_model, launch_embed(ea, e->cur));
     if (run_layers(e, rows, dev_of(m, m.row_pos), dev_of(m, m.row_stream), dev_of(m, m.row_ctx), false,
-                   nullptr, nullptr, 0, e->share_prefix ? dev_of(m, m.row_pfx) : nullptr)) return 1;
+                   nullptr, nullptr, 0, e->share_prefix ? dev_of(m, m.row_pfx) : nullptr,
+                   gather_in_norm ? dev_of(m, m.eidx) : nullptr)) return 1;
     return run_head_and_sample(e, m, rows, nullptr, B);
 }
 

@@ -63,14 +63,25 @@ template <int NSPLIT>
 __global__ __launch_bounds__(SLAB_NORM_THREADS) void slab_add_rmsnorm_kernel(const float* __restrict__ slab,
                                                                size_t slab_stride, bf16_t* __restrict__ res,
                                                                const bf16_t* __restrict__ w, bf16_t* __restrict__ xn,
-                                                               float eps, int xn_tiled) {
+                                                               float eps, int xn_tiled, const bf16_t* __restrict__ emb,
+                                                               const int32_t* __restrict__ emb_slot,
+                                                               const int32_t* __restrict__ last_token) {
     constexpr int d = 1024;
     __shared__ float part[2];
     const size_t row = blockIdx.x;
     const int tid = threadIdx.x, c = tid * 8;
     float z[8];
-    unpack8(*reinterpret_cast<const u32x4*>(res + row * d + c), z);
     const u32x4 wv = *reinterpret_cast<const u32x4*>(w + c);
+    if (NSPLIT == 0 && emb != nullptr) {
+        // first norm of a decode step: the row is the embedding of the token its request sampled last
+        // (models/t3/t3.py:503-514), fetched here and stored as the residual row, instead of by a launch of its own
+        const int id = last_token[emb_slot[row]];
+        const u32x4 ev = *reinterpret_cast<const u32x4*>(emb + (size_t)id * d + c);
+        *reinterpret_cast<u32x4*>(res + row * d + c) = ev;
+        unpack8(ev, z);
+    } else {
+        unpack8(*reinterpret_cast<const u32x4*>(res + row * d + c), z);
+    }
     if constexpr (NSPLIT > 0) {
         norm_fold8<NSPLIT>(slab + row * d + c, slab_stride, z);
         *reinterpret_cast<u32x4*>(res + row * d + c) = pack8(z);
@@ -86,16 +97,18 @@ __global__ __launch_bounds__(SLAB_NORM_THREADS) void slab_add_rmsnorm_kernel(con
 }
 
 int launch_slab_add_rmsnorm(const float* slab, int nsplit, bf16_t* res, const bf16_t* w, bf16_t* xn, int rows, int d,
-                            float eps, hipStream_t st, bool xn_tiled) {
+                            float eps, hipStream_t st, bool xn_tiled, const bf16_t* emb, const int32_t* emb_slot,
+                            const int32_t* last_token) {
+    T3_REQUIRE(emb == nullptr || (nsplit == 0 && emb_slot && last_token), "slab_add_rmsnorm: the embedding gather belongs to the first norm");
     T3_REQUIRE(rows >= 1 && d == 1024, "slab_add_rmsnorm: d must be 1024");
     static_assert(SLAB_NORM_THREADS == 128, "8 columns per thread, two waves per row");
     T3_REQUIRE(nsplit == 0 || (slab != nullptr && nsplit == GEMM_SLAB_SPLIT), "slab_add_rmsnorm: nsplit must be 0 or the split count");
     if (nsplit == 0)
         T3_LAUNCH(slab_add_rmsnorm_kernel<0>, dim3(rows), dim3(SLAB_NORM_THREADS), 0, st, slab, (size_t)rows * d, res, w, xn, eps,
-                  (int)xn_tiled);
+                  (int)xn_tiled, emb, emb_slot, last_token);
     else
         T3_LAUNCH(slab_add_rmsnorm_kernel<GEMM_SLAB_SPLIT>, dim3(rows), dim3(SLAB_NORM_THREADS), 0, st, slab, (size_t)rows * d, res, w, xn,
-                  eps, (int)xn_tiled);
+                  eps, (int)xn_tiled, emb, emb_slot, last_token);
     T3_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -180,7 +180,8 @@ int launch_gemm_prompt(int epi, const GemmArgs& a, hipStream_t st);
 // res = bf16(bf16(sum_s slab[s]) + res) when slab != nullptr (nsplit slabs of [rows, d] fp32);
 // xn = rmsnorm(res) * w.  One pass, the row stays in registers.
 int launch_slab_add_rmsnorm(const float* slab, int nsplit, bf16_t* res, const bf16_t* w, bf16_t* xn, int rows, int d,
-                            float eps, hipStream_t st, bool xn_tiled = false);
+                            float eps, hipStream_t st, bool xn_tiled = false, const bf16_t* emb = nullptr,
+                            const int32_t* emb_slot = nullptr, const int32_t* last_token = nullptr);
 int launch_repack(const bf16_t* w, bf16_t* wt, int N, int K, hipStream_t st);
 // W[N,K] bf16 -> int8 pair tiles (offset binary) + scale[N] = absmax(row) / 127 (1 for an all-zero row)
 int launch_quantize(const bf16_t* w, uint8_t* wq, float* scale, int N, int K, hipStream_t st);

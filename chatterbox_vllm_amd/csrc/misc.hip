@@ -190,7 +190,7 @@ int launch_embed(const EmbedArgs& a, hipStream_t st) {
 //            counter-based generator keyed by (seed, step, column)
 // The chosen column is marked in `seen` and the un-offset id stored for the next step.
 // ------------------------------------------------------------------------------------
-#define SAMPLE_THREADS 256
+#define SAMPLE_THREADS 1024     // 8 columns per thread: the whole speech vocabulary in one pass
 #define SAMPLE_MAX_VOCAB 8448
 
 __device__ __forceinline__ unsigned mix32(unsigned x) {
@@ -242,6 +242,7 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void sample_kernel(SampleArgs a) {
     const int slot = a.slot ? a.slot[i] : i;
     uint8_t* seen = a.seen + (size_t)slot * a.seen_stride;
     const float pen = a.rep_penalty[i];
+    const float T = a.temperature ? a.temperature[i] : 0.f;          // fetched up front, not behind the argmax
     const bf16_t* lc = a.logits + (size_t)rc * a.ldl;
     const bf16_t* lu = ru >= 0 ? a.logits + (size_t)ru * a.ldl : nullptr;
     float* ol = a.out_logits ? a.out_logits + (size_t)slot * (a.vocab + 1000) : nullptr;
@@ -288,7 +289,6 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void sample_kernel(SampleArgs a) {
     best = block_argmax(best, shm);
     int tok = best.i;
 
-    const float T = a.temperature ? a.temperature[i] : 0.f;
     if (T >= 1e-5f) {
         // logits / T ; everything below is relative to the maximum so no overflow
         const float lmax = best.v / T;

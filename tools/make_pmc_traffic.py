@@ -7,14 +7,15 @@ import json, sys
 tag = sys.argv[1]
 f = json.load(open(tag + "_pmc_fetch.json"))["FETCH_SIZE"]
 w = json.load(open(tag + "_pmc_write.json"))["WRITE_SIZE"]
-# gemm_stream_kernel<NB, MT, KW, KT, EPI, W8>: the full-batch (33-64 row) bf16 variants of the decode step
+# gemm_stream_kernel<NB, MT, KW, KT, EPI, W8, FN>: the full-batch (33-64 row) bf16 variants of the decode step
 classes = {
     "attn_decode": ["attn_decode_kernel"],
-    "gemm_gateup_silu": ["void gemm_stream_kernel<2, 4, 8, 4, 2, false>"],
-    "gemm_qkv_rope": ["void gemm_stream_kernel<2, 2, 8, 4, 3, false>"],
-    "gemm_down_resid": ["void gemm_stream_kernel<2, 4, 8, 2, 4, false>"],
-    "gemm_o_resid": ["void gemm_stream_kernel<2, 4, 4, 1, 4, false>"],
+    "gemm_gateup_silu": ["void gemm_stream_kernel<2, 4, 8, 4, 2, false, -1>"],
+    "gemm_qkv_rope": ["void gemm_stream_kernel<2, 2, 8, 4, 3, false, -1>"],
+    "gemm_down_resid": ["void gemm_stream_kernel<2, 4, 8, 2, 4, false, -1>"],
+    "gemm_o_resid": ["void gemm_stream_kernel<2, 4, 4, 1, 4, false, -1>"],
     "add_rmsnorm": ["void slab_add_rmsnorm_kernel<8>"],
+    "gemm_head": ["void gemm_stream_kernel<3, 4, 8, 4, 0, false, -1>"],
 }
 out = {}
 for cls, names in classes.items():

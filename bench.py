@@ -5,6 +5,9 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
+`python bench.py --gpus N` with N > 1 from a plain shell starts its own N ranks (one child `torch.distributed.run`,
+before this process has made any GPU call) and relays rank 0's line.
+
 One STEP = one pass of the whole hot path over one batch of synthetic requests: the
 154-chunk job of the reference's benchmark.py (text-length histogram of
 docs/benchmark-text-1.txt, tests/golden/ref_text_fixture.json) is queued on one engine with 32
@@ -14,14 +17,16 @@ penalty 2.0, prompt + output <= max_model_len 1000.  Random weights never emit t
 reliably, so every request runs to a fixed output length proportional to its text length with
 the README-implied mean of 394 tokens.  Each rank runs the same job on its own GPU (weak
 scaling: requests are independent; the only collective is the final all-gather of ids); value =
-tokens of all ranks / max-over-ranks time.
+tokens of all ranks / max-over-ranks time.  --scaling strong deals ONE job (and the slots) over the ranks instead.
 
-Other configurations of the same engine (not the driver's default line; results are quoted in DESIGN.md):
+Other configurations of the same engine:
   --workload single         one request, CFG off (one KV stream), 152 text ids, decoded to position 1000
   --workload multilingual   multilingual vocabulary (2454), fr + zh chunk lengths of the reference's
                             benchmark-multilingual-{fr,zh}.py mixed in one queue, 4 voices; use --concurrency 64
   --quantization int8       W8A16 backbone weights; with --concurrency 128 --repeat-job 2 the int8 / batch-128 case
-                            (under torchrun the 128 slots are divided over the ranks)
+On one GPU the default command also runs them as short extra legs (one timed pass each) and reports them under
+"other_configs", each with its own roofline object; so does the headline job under first-come-first-served admission
+("fcfs_value") and with the uncond row that gets no attention ("uncond_no_attention_value").
 
 Besides the throughput line this prints, in the same JSON object:
   roofline      the dominant kernel's algorithmic bytes / its HIP-event time, measured in a
@@ -29,6 +34,7 @@ Besides the throughput line this prints, in the same JSON object:
   cpu_baseline  the CPU oracle (a port of the same arithmetic) timed on a bounded slice of the job
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -39,9 +45,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from chatterbox_vllm_amd.config import T3ModelConfig, SPEECH_TOKEN_OFFSET  # noqa: E402
+from chatterbox_vllm_amd.config import T3ModelConfig, SPEECH_TOKEN_OFFSET  # noqa: E402,F401
 from chatterbox_vllm_amd import weights as W  # noqa: E402
-from chatterbox_vllm_amd.engine import T3Engine, SamplingParams  # noqa: E402
 
 METRIC = "T3 speech-tokens/sec/GPU at batch=32, max_len=1000; 1/2/4/8-GPU scaling"
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak
@@ -88,8 +93,9 @@ def build_job(seed: int, n_requests: int = 0, workload: str = "benchmark", repea
     return job
 
 
-def run_job(eng: T3Engine, job, conds, stats=None):
+def run_job(eng, job, conds, stats=None):
     """Queue the whole job and run the engine dry.  Returns (#tokens, ids per request)."""
+    from chatterbox_vllm_amd.engine import SamplingParams
     rids = []
     for text, out_len, voice in job:
         sp = SamplingParams(temperature=0.0, repetition_penalty=2.0, max_tokens=out_len, stop_token_ids=None)
@@ -127,16 +133,173 @@ def cpu_baseline(cfg, sd, job, conds, paired=True):
                       f"prefill + 96 greedy tokens each, batched decode, {dt:.1f} s of CPU time"}, out, sub
 
 
+def _kernel_source_sha():
+    """sha256 (16 hex digits) over the kernel sources, so that a committed counter profile can be tied to the build."""
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "chatterbox_vllm_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".h")):
+            with open(os.path.join(csrc, name), "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def _pmc_traffic(kernel_class):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes over this same
-    workload (FETCH_SIZE doubled as gfx950 needs, plus WRITE_SIZE); None when no such file is in the tree."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+    """HBM bytes per launch of a kernel class from the committed rocprofv3 --pmc passes over the default job
+    (FETCH_SIZE doubled as gfx950 needs, plus WRITE_SIZE).  It is a committed profile, not a measurement of this run:
+    returned only when the file says it was taken from the kernel sources this tree holds."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as fh:
             rec = json.load(fh)
     except (OSError, ValueError):
         return None
+    if rec.get("kernel_source_sha16") not in (None, _kernel_source_sha()):
+        return None
     return rec.get(kernel_class)
+
+
+def roofline_of(eng, job, conds, use_pmc):
+    """One more pass of the job with every launch bracketed by HIP events bound to its dispatch; the roofline object of
+    the dominant HBM-streaming kernel plus the per-class breakdown."""
+    eng.set_kernel_timing(True)
+    t1 = time.perf_counter()
+    run_job(eng, job, conds)
+    timed_pass = time.perf_counter() - t1
+    kd, kp = eng.kernel_times("decode"), eng.kernel_times("prefill")
+    eng.set_kernel_timing(False)
+    tot = sum(v["ms"] for v in kd.values()) + sum(v["ms"] for v in kp.values())
+    # the dominant kernel among those that stream from HBM (K/V or weights); the row-wise kernels (norm, embedding,
+    # sampler) work out of L2 and have no HBM roofline
+    streaming = {k: v for k, v in kd.items() if k.startswith(("attn_", "gemm_"))}
+    name, dom = max(streaming.items(), key=lambda kv: kv[1]["ms"])
+    per_launch_bytes = dom["bytes"] / dom["launches"]
+    per_launch_s = dom["ms"] / dom["launches"] / 1000.0
+    achieved = per_launch_bytes / per_launch_s / 1e9
+    roof = {
+        "bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+        "avg_launch_us": round(per_launch_s * 1e6, 2),
+        "algorithmic_bytes_per_launch": int(per_launch_bytes),
+        "launches": dom["launches"], "share_of_gpu_time": round(dom["ms"] / tot, 3),
+    }
+    pmc = _pmc_traffic(name) if use_pmc else None
+    if pmc is not None:
+        roof["traffic"] = pmc["bytes_per_launch"]
+        roof["traffic_source"] = "committed profile (profiles/pmc_traffic.json): " + pmc["source"]
+    breakdown = {
+        ph: {k: {"ms": round(v["ms"], 2), "launches": v["launches"],
+                 "GBps": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1)} for k, v in d.items()}
+        for ph, d in (("decode", kd), ("prefill", kp))}
+    breakdown["event_timed_pass_s"] = round(timed_pass, 3)
+    return roof, breakdown
+
+
+def workload_text(workload, conc):
+    return {
+        "benchmark": "benchmark.py 154-chunk job (docs/benchmark-text-1.txt length histogram), "
+                     f"{conc} concurrent requests, CFG-paired scale 3.0, greedy, max_model_len 1000, "
+                     f"output length ~ text length with mean {MEAN_OUT}; per GPU",
+        "single": "one request, CFG off (single KV stream), 152 text ids, greedy, decoded to position 1000",
+        "multilingual": "multilingual vocabulary 2454, fr + zh chunk lengths of benchmark-multilingual-{fr,zh}.py "
+                        f"mixed in one queue of 128 requests, 4 voices, {conc} concurrent requests, CFG-paired "
+                        "scale 3.0, greedy, max_model_len 1000; per GPU"}[workload]
+
+
+def make_engine(cfg, sd, conc, paired, device, args, quantization, policy, uncond_attends=True):
+    from chatterbox_vllm_amd.engine import T3Engine
+    return T3Engine(cfg, sd, max_model_len=MAX_MODEL_LEN, max_num_seqs=conc, cfg_scale=CFG_SCALE,
+                    cfg_paired=paired, device=device, max_prefill_rows=args.max_prefill_rows,
+                    quantization=None if quantization == "none" else quantization,
+                    scheduling_policy=policy, uncond_attends=uncond_attends,
+                    prefix_sharing=not args.no_prefix_sharing)
+
+
+def extra_leg(args, device, sd_cache, workload, conc, quantization, repeat, label):
+    """One short leg of another BASELINE configuration on this GPU: one warm-up pass, one timed pass, one event-timed
+    pass.  Returns the record that goes under "other_configs"."""
+    single = workload == "single"
+    mtl = workload == "multilingual"
+    key = "mtl" if mtl else "en"
+    if key not in sd_cache:
+        cfg = (T3ModelConfig.multilingual if mtl else T3ModelConfig.english)(n_layers=args.layers)
+        sd_cache[key] = (cfg, W.synthetic_state_dict(cfg, seed=1234))
+    cfg, sd = sd_cache[key]
+    conds = [W.synthetic_cond_emb(v) for v in range(4)]
+    job = build_job(seed=7, n_requests=args.requests, workload=workload, repeat=repeat)
+    eng = make_engine(cfg, sd, conc, not single, device, args, quantization, args.policy)
+    run_job(eng, job, conds)                                   # warm-up: graphs captured, caches warm
+    stats = {"decode_steps": 0, "decode_rows": 0, "decode_ctx_tokens": 0}
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    n, _ = run_job(eng, job, conds, stats)
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    rec = {"config": label, "workload": workload_text(workload, conc), "value": round(n / dt, 2), "unit": "tokens/s",
+           "seconds": round(dt, 3), "requests": len(job), "concurrency": conc,
+           "weights": "int8 (W8A16)" if quantization == "int8" else "bf16",
+           "decode": {"steps": stats["decode_steps"],
+                      "mean_rows": round(stats["decode_rows"] / max(1, stats["decode_steps"]), 2),
+                      "mean_ctx": round(stats["decode_ctx_tokens"] / max(1, stats["decode_rows"]), 1)}}
+    if not args.no_roofline:
+        rec["roofline"], _ = roofline_of(eng, job, conds, use_pmc=False)
+    eng.shutdown()
+    return rec
+
+
+def launch_ranks(args) -> int:
+    """`bench.py --gpus N` from a plain shell: start N ranks as ONE child process (torch.distributed.run) and pass its
+    exit code on.  Called before this process has made any GPU call; this process only waits."""
+    import socket
+    import subprocess
+    if args.backend == "nccl" and not args.rehearse:
+        n = torch.cuda.device_count()                      # counts devices without initialising the GPU
+        if n < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} needs {args.gpus} GPUs, {n} visible "
+                  "(--backend gloo lets ranks share a GPU to rehearse the multi-rank path)", file=sys.stderr)
+            return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
+class _RehearsalEngine:
+    """--rehearse: no GPU and no library; stands in for the engine so that the launcher, the rendezvous, the broadcast,
+    the gather and the reduction can be run on a CPU-only machine.  Its line says "rehearsal" and is not a measurement."""
+
+    def __init__(self):
+        self._q = []
+        self._n = 0
+
+    def add_request(self, text, cond, sp):
+        self._n += 1
+        self._q.append([self._n, min(4, sp.max_tokens), len(text)])
+        return self._n
+
+    def has_unfinished(self):
+        return bool(self._q)
+
+    def step(self):
+        out = []
+        for r in self._q:
+            r[1] -= 1
+            out.append((r[0], 1000 + (7 * r[2] + r[1]) % 6000, "length" if r[1] == 0 else None))
+        self._q = [r for r in self._q if r[1] > 0]
+        return out
+
+    def stats(self):
+        class S:
+            decode_requests = 0
+        return S()
+
+    def shutdown(self):
+        pass
 
 
 def main():
@@ -154,6 +317,9 @@ def main():
                     help="admission order of the queue: longest request first keeps the 32 slots full until the queue "
                          "is nearly dry (mean 31 of 32 slots busy against 26 with first come first served); "
                          "token ids are the same under both")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: every rank runs the whole job with all the slots.  strong: ONE job is dealt round-robin "
+                         "over the ranks and the slots are divided among them (config 4: 128 slots / N)")
     ap.add_argument("--uncond-no-attention", action="store_true",
                     help="engine mode cfg_paired=2: the uncond row has no attention and no KV (not the benchmark)")
     ap.add_argument("--max-prefill-rows", type=int, default=2048,
@@ -165,11 +331,21 @@ def main():
                          "multi-rank path on a box with fewer GPUs than ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="skip the short legs of the other configurations (FCFS, single stream, int8 x 128, multilingual x 64)")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="no GPU, no library: a stand-in engine, to run the launcher and the collectives on a CPU-only "
+                         "machine (gloo); the line it prints says so and is not a measurement")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.rehearse:
+        args.backend = "gloo"
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -180,32 +356,40 @@ def main():
         else:
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     coll_dev = torch.device("cpu") if args.backend == "gloo" else torch.device("cuda", local_rank)
 
     single = args.workload == "single"
     paired = not single
     conc = args.concurrency or (1 if single else CONCURRENCY)
-    if args.concurrency and world > 1 and args.quantization == "int8":
-        conc = max(1, args.concurrency // world)           # the int8 case divides its slots over the ranks
-    cfg = (T3ModelConfig.multilingual if args.workload == "multilingual" else T3ModelConfig.english)(n_layers=args.layers)
+    if args.scaling == "strong":
+        conc = max(1, conc // world)                       # the slots are divided over the ranks
+    n_layers = 0 if args.rehearse else args.layers
+    cfg = (T3ModelConfig.multilingual if args.workload == "multilingual" else T3ModelConfig.english)(n_layers=n_layers)
     sd = W.synthetic_state_dict(cfg, seed=1234)
     if dist is not None:
         # rank 0's checkpoint is the checkpoint: one RCCL broadcast of the weights over xGMI
         from chatterbox_vllm_amd.sharding import broadcast_state_dict
         sd = broadcast_state_dict(sd, src=0, device=coll_dev)
     conds = [W.synthetic_cond_emb(v) for v in range(4)]
-    job = build_job(seed=7 + rank, n_requests=args.requests, workload=args.workload, repeat=args.repeat_job)
-    eng = T3Engine(cfg, sd, max_model_len=MAX_MODEL_LEN, max_num_seqs=conc, cfg_scale=CFG_SCALE,
-                   cfg_paired=paired, device=local_rank, max_prefill_rows=args.max_prefill_rows,
-                   quantization=None if args.quantization == "none" else args.quantization,
-                   scheduling_policy=args.policy, uncond_attends=not args.uncond_no_attention,
-                   prefix_sharing=not args.no_prefix_sharing)
+    if args.scaling == "strong":
+        from chatterbox_vllm_amd.sharding import shard_indices
+        whole = build_job(seed=7, n_requests=args.requests, workload=args.workload, repeat=args.repeat_job)
+        job = [whole[i] for i in shard_indices(len(whole), world, rank)]
+    else:
+        job = build_job(seed=7 + rank, n_requests=args.requests, workload=args.workload, repeat=args.repeat_job)
+    if args.rehearse:
+        eng = _RehearsalEngine()
+    else:
+        eng = make_engine(cfg, sd, conc, paired, local_rank, args, args.quantization, args.policy,
+                          uncond_attends=not args.uncond_no_attention)
 
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize(local_rank)
+        if not args.rehearse:
+            torch.cuda.synchronize(local_rank)
 
     for _ in range(args.warmup):
         run_job(eng, job, conds)
@@ -219,17 +403,20 @@ def main():
         tokens += n
     barrier()
     dt = time.perf_counter() - t0
+    ranks_seen = 1
     if dist is not None:
         t = torch.tensor([dt], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        tk = torch.tensor([tokens], device=coll_dev, dtype=torch.int64)
+        tk = torch.tensor([tokens, 1], device=coll_dev, dtype=torch.int64)
         dist.all_reduce(tk, op=dist.ReduceOp.SUM)
-        total_tokens = int(tk.item())
+        total_tokens, ranks_seen = int(tk[0].item()), int(tk[1].item())
         # the job's result travels to rank 0 the way a sharded generate() returns it
         from chatterbox_vllm_amd.sharding import gather_token_ids
         gathered = gather_token_ids(last_ids, device=coll_dev)
-        assert rank != 0 or len(gathered) == world * len(job)
+        n_jobs = torch.tensor([len(job)], device=coll_dev, dtype=torch.int64)
+        dist.all_reduce(n_jobs, op=dist.ReduceOp.SUM)
+        assert len(gathered) == int(n_jobs.item())
     else:
         total_tokens = tokens
 
@@ -238,15 +425,10 @@ def main():
         result = {
             "metric": METRIC, "value": round(total_tokens / dt, 2), "unit": "tokens/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000 * dt / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": {
-                "benchmark": "benchmark.py 154-chunk job (docs/benchmark-text-1.txt length histogram), "
-                             f"{conc} concurrent requests, CFG-paired scale 3.0, greedy, max_model_len 1000, "
-                             f"output length ~ text length with mean {MEAN_OUT}; per GPU",
-                "single": "one request, CFG off (single KV stream), 152 text ids, greedy, decoded to position 1000",
-                "multilingual": "multilingual vocabulary 2454, fr + zh chunk lengths of benchmark-multilingual-{fr,zh}.py "
-                                f"mixed in one queue of 128 requests, 4 voices, {conc} concurrent requests, CFG-paired "
-                                "scale 3.0, greedy, max_model_len 1000; per GPU"}[args.workload],
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "bf16",
+            "data": "rehearsal: stand-in engine, no GPU work, not a measurement" if args.rehearse else "synthetic",
+            "ranks_seen": ranks_seen,
+            "config": {"workload": workload_text(args.workload, conc),
                        "requests_per_gpu": len(job), "tokens_per_step_per_gpu": tokens // max(1, args.steps),
                        "concurrency": conc, "layers": cfg.n_layers, "weights": "int8 (W8A16)" if args.quantization == "int8" else "bf16",
                        "admission": args.policy, "uncond_stream": "no attention, no KV" if args.uncond_no_attention else "own KV",
@@ -259,44 +441,50 @@ def main():
         }
 
     # ---- roofline: per-launch event timing of every kernel class over one more pass of the job
-    if rank == 0 and not args.no_roofline:
-        eng.set_kernel_timing(True)
-        t1 = time.perf_counter()
+    if rank == 0 and not args.no_roofline and not args.rehearse:
+        default_job = (args.workload == "benchmark" and args.quantization == "none" and not args.requests
+                       and not args.uncond_no_attention and args.layers == 30 and not args.concurrency)
+        result["roofline"], result["kernel_breakdown"] = roofline_of(eng, job, conds, use_pmc=default_job)
+
+    # ---- the same job under the admission order vLLM has (first come first served), driver-timed like the headline
+    extras = rank == 0 and world == 1 and not args.no_extra_legs and not args.rehearse and args.workload == "benchmark" \
+        and args.quantization == "none" and not args.uncond_no_attention
+    if extras and args.policy != "fcfs":
+        eng.set_schedule_policy("fcfs")
         run_job(eng, job, conds)
-        timed_pass = time.perf_counter() - t1
-        kd, kp = eng.kernel_times("decode"), eng.kernel_times("prefill")
-        eng.set_kernel_timing(False)
-        tot = sum(v["ms"] for v in kd.values()) + sum(v["ms"] for v in kp.values())
-        # the dominant kernel among those that stream from HBM (K/V or weights); the row-wise kernels (norm, embedding,
-        # sampler) work out of L2 and have no HBM roofline
-        streaming = {k: v for k, v in kd.items() if k.startswith(("attn_", "gemm_"))}
-        name, dom = max(streaming.items(), key=lambda kv: kv[1]["ms"])
-        per_launch_bytes = dom["bytes"] / dom["launches"]
-        per_launch_s = dom["ms"] / dom["launches"] / 1000.0
-        achieved = per_launch_bytes / per_launch_s / 1e9
-        result["roofline"] = {
-            "bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-            "avg_launch_us": round(per_launch_s * 1e6, 2),
-            "algorithmic_bytes_per_launch": int(per_launch_bytes),
-            "launches": dom["launches"], "share_of_gpu_time": round(dom["ms"] / tot, 3),
-        }
-        pmc = _pmc_traffic(name)
-        if pmc is not None:
-            result["roofline"]["traffic"] = pmc["bytes_per_launch"]
-            result["roofline"]["traffic_source"] = pmc["source"]
-        result["kernel_breakdown"] = {
-            ph: {k: {"ms": round(v["ms"], 2), "launches": v["launches"],
-                     "GBps": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1)} for k, v in d.items()}
-            for ph, d in (("decode", kd), ("prefill", kp))}
-        result["kernel_breakdown"]["event_timed_pass_s"] = round(timed_pass, 3)
+        torch.cuda.synchronize(local_rank)
+        t1 = time.perf_counter()
+        n_f, ids_f = run_job(eng, job, conds)
+        torch.cuda.synchronize(local_rank)
+        result["fcfs_value"] = round(n_f / (time.perf_counter() - t1), 2)
+        result["fcfs_ids_equal"] = ids_f == last_ids
     eng.shutdown()
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:          # the CPU leg is timed on the one-GPU run only
+    if extras:
+        # the uncond row without attention or KV (what a serving stack computes if it attends only the rows its
+        # scheduler counted); then BASELINE configs 2, 4 (one GPU's view: all 128 slots here) and 5
+        e2 = make_engine(cfg, sd, conc, paired, local_rank, args, "none", args.policy, uncond_attends=False)
+        run_job(e2, job, conds)
+        torch.cuda.synchronize(local_rank)
+        t1 = time.perf_counter()
+        n2, _ = run_job(e2, job, conds)
+        torch.cuda.synchronize(local_rank)
+        result["uncond_no_attention_value"] = round(n2 / (time.perf_counter() - t1), 2)
+        e2.shutdown()
+        cache = {"en": (cfg, sd)}
+        result["other_configs"] = [
+            extra_leg(args, local_rank, cache, "single", 1, "none", 1, "configs[1]: bf16, batch 1, CFG off"),
+            extra_leg(args, local_rank, cache, "benchmark", 128, "int8", 2,
+                      "configs[3] on one GPU: int8 weights, 128 slots, continuous admission from a 308-request queue"),
+            extra_leg(args, local_rank, cache, "multilingual", 64, "none", 1,
+                      "configs[4]: multilingual vocabulary, fr + zh mixed, 64 slots, 4 voices"),
+        ]
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.rehearse:   # the CPU leg is timed on the one-GPU run only
         cb, cpu_ids, sub = cpu_baseline(cfg, sd, job, conds, paired=paired)
         result["cpu_baseline"] = cb
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

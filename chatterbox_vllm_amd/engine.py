@@ -179,6 +179,13 @@ class T3Engine:
         _capi.check(self._lib, self._lib.t3_engine_get_stats(self._h, C.byref(s)))
         return s
 
+    def set_schedule_policy(self, policy: str) -> None:
+        """Admission order for requests added from now on: 'fcfs' (vLLM's) or 'longest_first'."""
+        if policy not in ("fcfs", "longest_first"):
+            raise ValueError("scheduling_policy must be 'fcfs' (vLLM's default) or 'longest_first'")
+        _capi.check(self._lib, self._lib.t3_engine_set_schedule_policy(self._h, int(policy == "longest_first")))
+        self.scheduling_policy = policy
+
     def set_timing(self, on: bool) -> None:
         _capi.check(self._lib, self._lib.t3_engine_set_timing(self._h, int(on)))
 

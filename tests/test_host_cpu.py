@@ -191,3 +191,30 @@ def test_benchmark_job_builder_follows_the_reference_histogram(text_fx):
     assert len(single) == 1 and 34 + len(single[0][0]) + 1 + single[0][1] == bench.MAX_MODEL_LEN
     mtl = bench.build_job(seed=7, workload="multilingual")
     assert len(mtl) == 128 and {v for _, _, v in mtl} == {0, 1, 2, 3} and {t[0] for t, _, _ in mtl} == {634, 725}
+
+
+def test_bench_starts_its_own_ranks_from_a_plain_shell():
+    """`python bench.py --gpus 2` without torchrun around it: the script starts the ranks itself (one child
+    torch.distributed.run, before any GPU call), rank 0's JSON line comes back on stdout, and `ranks_seen` (an
+    all-reduce over the group) says both ranks took part.  --rehearse swaps the engine for a stand-in so this runs
+    on a machine without a GPU; weak scaling (every rank its own job) and strong scaling (one job dealt out)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    for extra, per_rank in (([], [6, 6]), (["--scaling", "strong"], [4, 3])):
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse", "--steps", "1",
+                            "--warmup", "0", "--requests", "7" if extra else "6"] + extra,
+                           capture_output=True, text=True, timeout=300, env=env, cwd=root)
+        assert p.returncode == 0, p.stderr[-2000:]
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1
+        rec = json.loads(lines[0])
+        assert rec["n_gpus"] == 2 and rec["ranks_seen"] == 2 and rec["scaling"] == ("strong" if extra else "weak")
+        assert rec["config"]["requests_per_gpu"] == per_rank[0] and "rehearsal" in rec["data"]
+        assert rec["value"] > 0 and rec["config"]["tokens_per_step_per_gpu"] == 4 * per_rank[0]
+    # a rank count that disagrees with the launcher's world is an error, not an assertion trace
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--rehearse"],
+                       capture_output=True, text=True, timeout=120, cwd=root,
+                       env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert p.returncode == 0 and json.loads(p.stdout.strip().splitlines()[-1])["ranks_seen"] == 1

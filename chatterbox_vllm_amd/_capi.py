@@ -11,7 +11,7 @@ import os
 from functools import lru_cache
 
 LIB_NAME = "libt3hip.so"
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class T3Error(RuntimeError):
@@ -71,7 +71,9 @@ SIGNATURES = {
     "t3_last_error": ([], C.c_char_p),
     "t3_abi_version": ([], C.c_int),
     "t3_engine_create": ([C.POINTER(T3Config), C.POINTER(_P)], C.c_int),
+    "t3_engine_create_on_stream": ([C.POINTER(T3Config), _P, C.POINTER(_P)], C.c_int),
     "t3_engine_load_tensor": ([_P, C.c_char_p, _P, C.POINTER(C.c_int64), C.c_int32, C.c_int32], C.c_int),
+    "t3_engine_load_tensor_dev": ([_P, C.c_char_p, _P, C.POINTER(C.c_int64), C.c_int32, C.c_int32], C.c_int),
     "t3_engine_finalize": ([_P], C.c_int),
     "t3_engine_destroy": ([_P], C.c_int),
     "t3_engine_add_request": ([_P, C.c_int64, _I32P, C.c_int32, C.POINTER(C.c_float), C.POINTER(T3Sampling)], C.c_int),

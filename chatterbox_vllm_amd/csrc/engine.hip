@@ -87,6 +87,7 @@ struct Request {
     int reserve_pages = 0;            // worst-case pages per stream
     int have_pages = 0;               // pages allocated per stream
     bool aborted = false;
+    bool poisoned = false;            // ended on non-finite logits: its KV pages hold NaN and are cleared before reuse
     bool prefilling = false;          // admitted into a prefill job that has not been reported yet
     int voice = -1;                   // shared-prefix entry this request reads positions 0..33 from
     bool builds_voice = false;        // its prefill step also carries the voice's 34 rows
@@ -142,6 +143,7 @@ struct Pinned {
 struct t3_engine {
     t3_config cfg{};
     hipStream_t stream = nullptr;                       // main stream: decode steps, block-table uploads, step events
+    bool stream_owned = true;                           // false: the caller's stream (t3_engine_create_on_stream), not destroyed here
     hipStream_t pstream = nullptr;                      // prefill of the step's admissions (== stream in the synchronous modes)
     hipStream_t pstream_own = nullptr;                  // the second stream itself
     hipStream_t cur = nullptr;                          // the stream the phase being enqueued uses
@@ -172,8 +174,13 @@ struct t3_engine {
     int64_t n_pages = 0, layer_stride = 0;
     std::vector<int32_t> free_pages;
     int64_t reserved_unallocated = 0;                   // sum over running requests, in pages
-    Pinned<int32_t> block_table;                        // [n_streams][max_pages]
+    Pinned<int32_t> block_table;                        // [n_streams][max_pages]; the device copy serves the decode steps (main stream)
     bool block_table_dirty = true;
+    // A prefill job reads its own device copy, uploaded from its own pinned snapshot on the prefill stream: the job spans
+    // several decode steps, each of which may re-upload the decode copy.  One job is outstanding at a time.
+    int32_t* bt_prefill_d = nullptr;
+    int32_t* bt_prefill_stage[2] = {nullptr, nullptr};  // by step parity: with prefill inside pipelined steps two uploads can be queued
+    const int32_t* bt_cur = nullptr;                    // the copy the phase being enqueued reads
 
     // activations (shared by prefill and decode: steps execute in stream order)
     struct Bufs {
@@ -245,7 +252,7 @@ struct t3_engine {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 
     KvView kvview() const {
-        KvView v; v.pool = kv_pool; v.layer_stride = layer_stride; v.block_table = block_table.d;
+        KvView v; v.pool = kv_pool; v.layer_stride = layer_stride; v.block_table = bt_cur ? bt_cur : block_table.d;
         v.max_pages = max_pages; v.H = cfg.n_heads; v.hd = cfg.head_dim; return v;
     }
 };
@@ -470,9 +477,18 @@ int grow_pages(t3_engine* e, Request& r, int positions) {
 }
 
 void release_request(t3_engine* e, Request& r) {
+    const size_t page_elems = (size_t)2 * e->cfg.n_heads * T3_PAGE * e->cfg.head_dim;
     for (int u = 0; u < e->kv_per_req; ++u)
-        for (int p = 0; p < r.have_pages; ++p)
-            e->free_pages.push_back(e->block_table.h[(size_t)(r.slot * e->kv_per_req + u) * e->max_pages + p]);
+        for (int p = 0; p < r.have_pages; ++p) {
+            const int32_t pg = e->block_table.h[(size_t)(r.slot * e->kv_per_req + u) * e->max_pages + p];
+            // The attention kernels weight the unused positions of a page by zero, which does not silence a NaN: pages
+            // that a request with non-finite values wrote go back to the pool cleared (behind the steps that used them).
+            if (r.poisoned)
+                for (int li = 0; li < e->cfg.n_layers; ++li)
+                    (void)hipMemsetAsync(e->kv_pool + (size_t)li * e->layer_stride + (size_t)pg * page_elems, 0,
+                                         page_elems * sizeof(bf16_t), e->stream);
+            e->free_pages.push_back(pg);
+        }
     e->reserved_unallocated -= (int64_t)(r.reserve_pages - r.have_pages) * e->kv_per_req;
     if (r.voice >= 0) { e->voices[r.voice].refs--; r.voice = -1; }
 }
@@ -608,8 +624,11 @@ int run_prefill(t3_engine* e, const std::vector<Request*>& reqs) {
         }
     const int rows = row;
     e->kphase = 1;
-    if (sync_block_table(e)) return 1;                    // on the main stream
-    if (prefill_after_main(e)) return 1;
+    // the job's own snapshot of the block table (the step of this parity two calls back has completed: its snapshot is free)
+    std::memcpy(e->bt_prefill_stage[e->parity], e->block_table.h, sizeof(int32_t) * e->block_table.n);
+    T3_HIP_CHECK(hipMemcpyAsync(e->bt_prefill_d, e->bt_prefill_stage[e->parity], sizeof(int32_t) * e->block_table.n,
+                                hipMemcpyHostToDevice, e->cur));
+    e->bt_cur = e->bt_prefill_d;
     if (upload(e, m)) return 1;
     if (stage_check(e, "prefill_upload")) return 1;
     // seen rows
@@ -637,6 +656,7 @@ int run_prefill(t3_engine* e, const std::vector<Request*>& reqs) {
     e->stats.prefill_rows = rows;
     e->cur = e->stream;
     e->b = &e->bufs;
+    e->bt_cur = e->block_table.d;
     return 0;
 }
 
@@ -687,6 +707,7 @@ int run_decode(t3_engine* e, const std::vector<Request*>& reqs) {
     // with shared prefixes the rows of a voice fetch its 34 positions once between them
     e->cur_ctx_tokens = !e->share_prefix ? ctx_total
                                          : ctx_total - (int64_t)kCondRows * B * e->kv_per_req + (int64_t)kCondRows * voices_met;
+    e->bt_cur = e->block_table.d;
     if (sync_block_table(e)) return 1;
     if (upload(e, m)) return 1;
     e->kphase = 0;
@@ -729,7 +750,17 @@ int find_tensor(t3_engine* e, const std::string& name, int64_t d0, int64_t d1, b
 }  // namespace
 
 // =========================================================================================
+static int engine_create(const t3_config* cfg, hipStream_t caller_stream, bool on_caller_stream, t3_engine** out);
+
 extern "C" int t3_engine_create(const t3_config* cfg, t3_engine** out) {
+    return engine_create(cfg, nullptr, false, out);
+}
+
+extern "C" int t3_engine_create_on_stream(const t3_config* cfg, void* stream, t3_engine** out) {
+    return engine_create(cfg, static_cast<hipStream_t>(stream), true, out);
+}
+
+static int engine_create(const t3_config* cfg, hipStream_t caller_stream, bool on_caller_stream, t3_engine** out) {
     T3_REQUIRE(cfg && out, "null argument");
     T3_REQUIRE(cfg->d_model == 1024 && cfg->head_dim == 64 && cfg->n_heads * cfg->head_dim == cfg->d_model,
                "engine is built for d_model 1024 = 16 heads x 64");
@@ -751,7 +782,11 @@ extern "C" int t3_engine_create(const t3_config* cfg, t3_engine** out) {
     e->n_rows = c.max_num_seqs * e->rows_per_req;
     e->max_pages = pages_for(c.max_model_len);
     e->head_n = (c.speech_vocab + 15) / 16 * 16;
-    T3_HIP_CHECK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    if (on_caller_stream) {
+        e->stream = caller_stream; e->stream_owned = false;
+        if (caller_stream == nullptr) e->cfg.use_graphs = 0;      // the default stream cannot be captured
+    }
+    else T3_HIP_CHECK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     T3_HIP_CHECK(hipStreamCreateWithFlags(&e->pstream_own, hipStreamNonBlocking));
     e->pstream = e->pstream_own;
     e->cur = e->stream;
@@ -779,6 +814,10 @@ extern "C" int t3_engine_create(const t3_config* cfg, t3_engine** out) {
     if (e->block_table.alloc((size_t)(e->n_streams + e->n_voices) * e->max_pages)) return 1;
     for (int v = 0; v < e->n_voices; ++v)
         e->block_table.h[(size_t)(e->n_streams + v) * e->max_pages] = (int32_t)(e->n_pages + v);
+    T3_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->bt_prefill_d), sizeof(int32_t) * e->block_table.n));
+    for (int q = 0; q < 2; ++q)
+        T3_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&e->bt_prefill_stage[q]), sizeof(int32_t) * e->block_table.n));
+    e->bt_cur = e->block_table.d;
 
     // activations
     const int prefill_rows = c.max_prefill_rows * e->kv_per_req + (e->uncond_ghost ? c.max_num_seqs : 0);
@@ -821,8 +860,21 @@ extern "C" int t3_engine_create(const t3_config* cfg, t3_engine** out) {
     return 0;
 }
 
+static int load_tensor(t3_engine* e, const char* name, const void* data, const int64_t* shape, int32_t ndim, int32_t dtype,
+                       hipMemcpyKind kind);
+
 extern "C" int t3_engine_load_tensor(t3_engine* e, const char* name, const void* data, const int64_t* shape,
                                      int32_t ndim, int32_t dtype) {
+    return load_tensor(e, name, data, shape, ndim, dtype, hipMemcpyHostToDevice);
+}
+
+extern "C" int t3_engine_load_tensor_dev(t3_engine* e, const char* name, const void* data_dev, const int64_t* shape,
+                                         int32_t ndim, int32_t dtype) {
+    return load_tensor(e, name, data_dev, shape, ndim, dtype, hipMemcpyDeviceToDevice);
+}
+
+static int load_tensor(t3_engine* e, const char* name, const void* data, const int64_t* shape, int32_t ndim, int32_t dtype,
+                       hipMemcpyKind kind) {
     T3_REQUIRE(e && name && data && shape, "null argument");
     T3_REQUIRE(!e->finalized, "engine already finalized");
     T3_REQUIRE(dtype == 0, "only bf16 (dtype 0) tensors are accepted");
@@ -833,7 +885,7 @@ extern "C" int t3_engine_load_tensor(t3_engine* e, const char* name, const void*
     for (auto v : sh) { T3_REQUIRE(v > 0, "bad shape"); n *= (size_t)v; }
     bf16_t* p = nullptr;
     if (dmalloc(&p, n)) return 1;
-    T3_HIP_CHECK(hipMemcpy(p, data, n * sizeof(bf16_t), hipMemcpyHostToDevice));
+    T3_HIP_CHECK(hipMemcpy(p, data, n * sizeof(bf16_t), kind));    // blocking: the source is free when the call returns
     auto it = e->raw.find(name);
     if (it != e->raw.end()) { (void)hipFree(it->second.p); e->raw.erase(it); }
     e->raw[name] = t3_engine::Raw{p, sh};
@@ -922,7 +974,7 @@ extern "C" int t3_engine_finalize(t3_engine* e) {
 extern "C" int t3_engine_destroy(t3_engine* e) {
     if (!e) return 0;
     (void)hipSetDevice(e->cfg.device);
-    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    if (e->stream || !e->stream_owned) (void)hipStreamSynchronize(e->stream);
     if (e->pstream_own) (void)hipStreamSynchronize(e->pstream_own);
     for (auto& kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
     for (auto& kv : e->raw) (void)hipFree(kv.second.p);
@@ -944,6 +996,8 @@ extern "C" int t3_engine_destroy(t3_engine* e) {
 
     }
     e->block_table.release();
+    (void)hipFree(e->bt_prefill_d);
+    for (int q = 0; q < 2; ++q) if (e->bt_prefill_stage[q]) (void)hipHostFree(e->bt_prefill_stage[q]);
     for (auto* m : {&e->dm[0], &e->dm[1], &e->pm[0], &e->pm[1]}) {
         m->blk.release();
         if (m->out_tokens) (void)hipHostFree(m->out_tokens);
@@ -951,7 +1005,7 @@ extern "C" int t3_engine_destroy(t3_engine* e) {
     for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
     if (e->pjob_done) (void)hipEventDestroy(e->pjob_done);
     for (auto& ev : e->kpool) (void)hipEventDestroy(ev);
-    if (e->stream) (void)hipStreamDestroy(e->stream);
+    if (e->stream && e->stream_owned) (void)hipStreamDestroy(e->stream);
     if (e->pstream_own) (void)hipStreamDestroy(e->pstream_own);
     delete e;
     return 0;
@@ -1088,7 +1142,8 @@ void account_token(t3_engine* e, Request* r, int32_t tok, int64_t* out_req_ids, 
     }
     r->n_out++;
     int fin = 0;
-    if (tok == r->sp.stop_token) fin = 1;
+    if (tok < 0) { fin = 3; r->poisoned = true; }             // the sampler found no finite logit
+    else if (tok == r->sp.stop_token) fin = 1;
     else if (r->n_out >= r->limit) fin = 2;
     out_req_ids[k] = r->id; out_tokens[k] = tok; out_finished[k] = fin; ++k;
     if (!fin) return;

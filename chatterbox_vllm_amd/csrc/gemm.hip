@@ -386,11 +386,15 @@ int launch_quantize(const bf16_t* w, uint8_t* wq, float* scale, int N, int K, hi
 template <int NB, int MT, int KW, int KT, int EPI, bool W8, int FN = -1>
 static int launch_w(const GemmArgs& a, int nblocks, hipStream_t st, int ksplit) {
     constexpr size_t lds = (size_t)KW * NB * MT * 64 * sizeof(f32x4);
-    static bool attr_set = false;
-    if (!attr_set) {
+    // the attribute belongs to the kernel's copy on ONE device: set it once per device this variant is launched on
+    static bool attr_set[T3_MAX_DEVICES] = {};
+    int dev = 0;
+    T3_HIP_CHECK(hipGetDevice(&dev));
+    T3_REQUIRE(dev >= 0 && dev < T3_MAX_DEVICES, "gemm: device ordinal out of range");
+    if (!attr_set[dev]) {
         T3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_stream_kernel<NB, MT, KW, KT, EPI, W8, FN>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        attr_set[dev] = true;
     }
     const int groups = (a.M + MT * 16 - 1) / (MT * 16);
     T3_LAUNCH((gemm_stream_kernel<NB, MT, KW, KT, EPI, W8, FN>), dim3(nblocks, groups, ksplit), dim3(KW * 64), lds, st, a);

@@ -331,7 +331,12 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void sample_kernel(SampleArgs a) {
         tok = r.i;
     }
     if (tid == 0) {
-        a.out_tokens[i] = tok + 1000;
+        // A row without a finite maximum (NaN or all -inf logits: a bad checkpoint, a non-finite conditioning row) has no
+        // argmax: report -1 for the caller to turn into an error, and leave id 0 behind so that the next step's
+        // embedding gather and the seen row stay inside their tables.
+        const bool ok = (unsigned)tok < (unsigned)a.vocab;
+        if (!ok) tok = 0;
+        a.out_tokens[i] = ok ? tok + 1000 : -1;
         seen[tok + 1000] = 1;
         if (a.last_token) a.last_token[slot] = tok;
     }

@@ -13,6 +13,7 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 #define T3_PAGE 64               // tokens per KV page
 #define T3_WAVE 64
+#define T3_MAX_DEVICES 64        // device ordinals the per-device tables of the library cover
 
 __device__ __forceinline__ float bf2f(bf16_t x) { return __uint_as_float(((unsigned)x) << 16); }
 // round-to-nearest-even, NaN stays NaN (v_cvt_pk_bf16_f32)

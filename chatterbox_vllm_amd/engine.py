@@ -67,7 +67,7 @@ class RequestOutput:
     finished: bool = True
 
 
-_FINISH = {1: "stop", 2: "length"}
+_FINISH = {1: "stop", 2: "length", 3: "error"}
 
 
 class T3Engine:
@@ -81,7 +81,7 @@ class T3Engine:
                  cfg_paired: Optional[bool] = None, device: int = 0, enforce_eager: bool = False,
                  kv_pages: int = 0, max_prefill_rows: int = 2048, quantization: Optional[str] = None,
                  scheduling_policy: str = "fcfs", uncond_attends: bool = True, prefix_sharing: bool = True,
-                 max_voices: int = 0, **_ignored_vllm_kwargs):
+                 max_voices: int = 0, stream: Optional[int] = None, **_ignored_vllm_kwargs):
         if cfg_scale is None:                      # models/t3/t3.py:343
             cfg_scale = float(os.environ.get("CHATTERBOX_CFG_SCALE", "0.5"))
         if cfg_paired is None:
@@ -112,7 +112,12 @@ class T3Engine:
             use_graphs=int(not enforce_eager), weight_int8=int(quantization == "int8"), cfg_scale=self.cfg_scale, rms_eps=m.rms_eps,
             kv_pages=int(kv_pages), prefix_sharing=int(self.prefix_sharing), max_voices=int(max_voices))
         self._h = C.c_void_p()
-        _capi.check(self._lib, self._lib.t3_engine_create(C.byref(cfg), C.byref(self._h)))
+        # stream: a raw hipStream_t (e.g. torch.cuda.Stream().cuda_stream) the engine enqueues its decode iterations
+        # on, in order with the caller's work there; None = a stream of the engine's own
+        if stream is None:
+            _capi.check(self._lib, self._lib.t3_engine_create(C.byref(cfg), C.byref(self._h)))
+        else:
+            _capi.check(self._lib, self._lib.t3_engine_create_on_stream(C.byref(cfg), C.c_void_p(int(stream)), C.byref(self._h)))
         if scheduling_policy not in ("fcfs", "longest_first"):
             raise ValueError("scheduling_policy must be 'fcfs' (vLLM's default) or 'longest_first'")
         self.scheduling_policy = scheduling_policy
@@ -123,9 +128,17 @@ class T3Engine:
 
     # ---- weights -----------------------------------------------------------------
     def _load_tensor(self, name: str, t: torch.Tensor) -> None:
-        t = t.detach().to(device="cpu", dtype=torch.bfloat16).contiguous()
+        # a tensor already on the engine's GPU is handed over as a device pointer (no trip through host memory)
+        on_device = t.is_cuda and t.device.index == self.device
+        t = t.detach().to(dtype=torch.bfloat16).contiguous() if on_device else \
+            t.detach().to(device="cpu", dtype=torch.bfloat16).contiguous()
         shape = (C.c_int64 * t.dim())(*t.shape)
-        _capi.check(self._lib, self._lib.t3_engine_load_tensor(self._h, name.encode(), _capi.ptr(t), shape, t.dim(), 0))
+        if on_device:
+            torch.cuda.current_stream(self.device).synchronize()      # the library copies on its own: producers must be done
+            load = self._lib.t3_engine_load_tensor_dev
+        else:
+            load = self._lib.t3_engine_load_tensor
+        _capi.check(self._lib, load(self._h, name.encode(), _capi.ptr(t), shape, t.dim(), 0))
 
     def _load(self, state_dict: Dict[str, torch.Tensor]) -> None:
         keep, self.skipped_tensors = route_checkpoint(state_dict.items(), self.model_config)
@@ -166,7 +179,11 @@ class T3Engine:
             self._step_bufs = ((C.c_int64 * cap)(), (C.c_int32 * cap)(), (C.c_int32 * cap)(), C.c_int32(0))
         rid, tok, fin, n = self._step_bufs
         _capi.check(self._lib, self._lib.t3_engine_step(self._h, rid, tok, fin, cap, C.byref(n)))
-        return [(rid[i], tok[i], _FINISH.get(fin[i])) for i in range(n.value)]
+        out = [(rid[i], tok[i], _FINISH.get(fin[i])) for i in range(n.value)]
+        bad = [r for r, _, f in out if f == "error"]
+        if bad:                                 # the library has already ended those requests
+            raise _capi.T3Error(f"request(s) {bad}: logits without a finite maximum (non-finite weights or conditioning)")
+        return out
 
     def has_unfinished(self) -> bool:
         return bool(self._lib.t3_engine_has_unfinished(self._h))

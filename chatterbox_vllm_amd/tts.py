@@ -125,7 +125,12 @@ class ChatterboxTTS:
         conds = None
         if (ckpt_dir / "conds.pt").is_file():
             conds = torch.load(ckpt_dir / "conds.pt", weights_only=True, map_location="cpu")
-        return cls._build(sd, cls.variant_config(variant), tok, target_device=target_device,
+        cfg = cls.variant_config(variant)
+        # the backbone's depth is the checkpoint's (30 for the published ones): a cut-down checkpoint loads as what it is
+        depth = 1 + max((int(k.split(".")[2]) for k in sd if k.startswith("tfmr.layers.")), default=-1)
+        if depth != cfg.n_layers:
+            cfg = T3ModelConfig(n_layers=depth, text_vocab=cfg.text_vocab)
+        return cls._build(sd, cfg, tok, target_device=target_device,
                           max_model_len=max_model_len, compile=compile, max_batch_size=max_batch_size,
                           variant=variant, default_conds=conds, **kwargs)
 

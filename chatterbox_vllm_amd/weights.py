@@ -59,6 +59,48 @@ def synthetic_state_dict(cfg: T3ModelConfig, seed: int = 1234) -> Dict[str, torc
     return sd
 
 
+DECISIVE_ACTIVE = 96          # speech ids that carry the structure of ``decisive_state_dict``
+
+
+def decisive_state_dict(cfg: T3ModelConfig, seed: int = 1234, n_active: int = DECISIVE_ACTIVE, emb_scale: float = 4.0,
+                        gamma: float = 0.9, second: float = 0.75) -> Dict[str, torch.Tensor]:
+    """A seeded checkpoint whose greedy choice is decisive at every decode step, for tests that require token ids to
+    be EQUAL between two implementations that round alike but sum in different orders.
+
+    ``synthetic_state_dict`` gives nearly flat logits: 8194 Gaussian values whose top-2 gap is a few bf16 ulp, so two
+    correct implementations may legitimately pick different ids.  Here ``n_active`` speech ids get embeddings large
+    enough to dominate the residual stream, and the speech head maps the direction of an active id ``a`` onto two
+    successors: ``first(a)`` with weight ``gamma`` and ``alt(a)`` with ``second * gamma``.  After token ``a`` the
+    logit of ``first(a)`` stands out (about 24, ``alt(a)`` 18, against a background of standard deviation 0.7); once
+    ``first(a)`` has been emitted the repetition penalty 2.0 halves it and ``alt(a)`` wins (18 against 12; with both
+    emitted 12 against 9), so the walk depends on the request's history
+    and, for multilingual prompts, on which text ids collide with speech columns.  Half of the active ids lie below
+    1454 (the columns multilingual text ids can reach).  A few ids lead to the stop id, so some walks end on "stop".
+    The FIRST token of a request is not structured: it comes from the start-of-speech row and depends on the
+    whole prompt, as with the flat checkpoint; tests pick prompts whose first step happens to be decisive.
+    Everything else (backbone, text tables, position tables) is ``synthetic_state_dict``'s."""
+    sd = synthetic_state_dict(cfg, seed)
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed + 77)
+    low = torch.randperm(1454, generator=g)[: n_active // 2]
+    high = 1454 + torch.randperm(6561 - 1454, generator=g)[: n_active - n_active // 2]
+    act = torch.cat([low, high])
+    emb = sd["speech_emb.weight"].to(torch.float32)
+    emb[act] = torch.randn(n_active, cfg.d_model, generator=g) * emb_scale
+    first = act[torch.randint(0, n_active, (n_active,), generator=g)]
+    alt = act[torch.randint(0, n_active, (n_active,), generator=g)]
+    stop_id = 6562                                        # modules/t3_config.py:9 (stop_speech_token)
+    first[torch.randperm(n_active, generator=g)[:3]] = stop_id
+    head = sd["speech_head.weight"].to(torch.float32)
+    unit = emb[act] / (emb_scale * math.sqrt(cfg.d_model))
+    for i in range(n_active):
+        head[first[i]] += gamma * unit[i]
+        head[alt[i]] += second * gamma * unit[i]
+    sd["speech_emb.weight"] = emb.to(torch.bfloat16)
+    sd["speech_head.weight"] = head.to(torch.bfloat16)
+    return sd
+
+
 def synthetic_cond_emb(voice: int = 0, d_model: int = 1024, seed: int = 4321) -> torch.Tensor:
     """Stand-in for ``T3CondEnc`` output: fp32 [34, d_model] on the CPU, which is what
     ``get_audio_conditionals`` hands to the engine (src/chatterbox_vllm/tts.py:240-247)."""

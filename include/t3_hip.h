@@ -5,8 +5,8 @@
  * declared here: plain pointers and sizes, int status codes, no C++ or torch types.
  * Status 0 = success; on failure t3_last_error() returns a message for the calling
  * thread.  Pointers named *_dev are device (HIP) addresses, everything else is host
- * memory.  All device work of a call is enqueued on the engine's own HIP stream (or
- * on the `stream` argument for the per-op entry points; 0 = the default stream).
+ * memory.  All device work of a call is enqueued on the engine's own HIP stream, or on the caller's when the engine
+ * was made by t3_engine_create_on_stream (per-op entry points: on their `stream` argument; 0 = the default stream).
  *
  * The reference has no native code of its own: the arithmetic of this path runs
  * inside the third-party vLLM wheel.  Each entry point therefore cites the Python
@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define T3_ABI_VERSION 2
+#define T3_ABI_VERSION 3
 
 typedef struct t3_engine t3_engine;
 
@@ -83,12 +83,22 @@ int t3_abi_version(void);
 /* ---- engine life cycle: stands in for vllm.LLM.__init__ (tts.py:140) and
  *      T3VllmModel.__init__/load_weights (models/t3/t3.py:305-379) ---------------- */
 int t3_engine_create(const t3_config* cfg, t3_engine** out);
+/* The same engine with the caller's HIP stream (a hipStream_t; 0 = the default stream) as its main stream: decode
+ * iterations, uploads and the iteration events are enqueued there, in order with the caller's own work on that stream.
+ * The stream stays the caller's (it must outlive the engine; t3_engine_destroy synchronises it and leaves it alone).
+ * Prompts still run beside the decode iterations on a second stream of the engine's own, which starts behind what the
+ * main stream holds. */
+int t3_engine_create_on_stream(const t3_config* cfg, void* stream, t3_engine** out);
 /* `name` is the checkpoint tensor name routed by t3.py:347-369 (tfmr.*, text_emb.weight,
  * speech_emb.weight, text_pos_emb.emb.weight, speech_pos_emb.emb.weight,
  * speech_head.weight) or "rope.cos_sin" ([max_pos, head_dim] bf16, cos|sin).
  * `data` is host memory holding bf16 (dtype 0) in row-major `shape`. */
 int t3_engine_load_tensor(t3_engine* e, const char* name, const void* data,
                           const int64_t* shape, int32_t ndim, int32_t dtype);
+/* The same from DEVICE memory on the engine's device (e.g. the storage of a PyTorch-ROCm tensor): borrowed for the
+ * duration of the call, which copies it and returns when the copy is complete. */
+int t3_engine_load_tensor_dev(t3_engine* e, const char* name, const void* data_dev,
+                              const int64_t* shape, int32_t ndim, int32_t dtype);
 /* Repack the loaded matrices into the streaming tile order; must follow the last load. */
 int t3_engine_finalize(t3_engine* e);
 int t3_engine_destroy(t3_engine* e);
@@ -102,7 +112,8 @@ int t3_engine_add_request(t3_engine* e, int64_t req_id, const int32_t* text_ids,
 /* One scheduler iteration: admit + prefill new requests, decode one token for every
  * running request.  out_* have room for `cap` entries; *n_out receives the number of
  * (req_id, token, finished) triples reported.  finished: 0 running, 1 stop token,
- * 2 length.  Tokens are in the +1000 id space, the stop token is reported.
+ * 2 length, 3 error: the request's logits had no finite maximum (NaN weights or conditioning); its token is -1
+ * and the request has ended.  Tokens are in the +1000 id space, the stop token is reported.
  * Iterations are pipelined one deep: a call launches the next iteration and reports the
  * previous one, so a call may report nothing (the first after admission) and, when a
  * measuring mode has just been switched on, two iterations' triples in order.  The prompts of

@@ -102,3 +102,31 @@ def test_french_prompt_through_multilingual_tts(text_fx, monkeypatch):
     with pytest.raises(ValueError):
         tts.generate("a", language_id="xx")
     tts.shutdown()
+
+
+def test_from_local_on_a_checkpoint_directory(tmp_path, golden_dir, monkeypatch):
+    """ChatterboxTTS.from_local (reference: tts.py:91-158) on a directory holding a 2-layer seeded checkpoint as
+    safetensors, a tokenizer.json (tiny BPE vocabulary of the tests) and conds.pt: the real engine is built from
+    what the files hold, the default voice is encoded on the GPU from conds.pt, and generate() gives the ids that
+    an engine built from the same tensors in memory gives for the same token ids and conditioning."""
+    from test_host_cpu import _write_checkpoint_dir
+    from chatterbox_vllm_amd.engine import T3Engine, SamplingParams
+    monkeypatch.setenv("CHATTERBOX_DETERMINISTIC", "1")
+    monkeypatch.setenv("CHATTERBOX_CFG_SCALE", "0.5")
+    cfg, sd = _write_checkpoint_dir(str(tmp_path), golden_dir, n_layers=2)
+    tts = ChatterboxTTS.from_local(str(tmp_path), max_model_len=200, max_batch_size=2)
+    assert tts.t3_config.n_layers == 2 and sorted(tts.t3.skipped_tensors)[-1] == "text_head.weight"
+    out = tts.generate(["Hi there.", "the inn"], max_tokens=20)
+    ros = tts.last_request_outputs
+    assert ros[0].prompt == "[START]Hi there.[STOP]" and ros[0].prompt_token_ids == [255, 36, 11, 2, 62, 20, 7, 55, 0]
+    cond = tts.get_audio_conditionals(None)[1]
+    assert cond.shape == (34, 1024) and cond.dtype == torch.float32 and cond.device.type == "cpu"
+    tts.shutdown()
+    eng = T3Engine(cfg, {k: v for k, v in sd.items() if not k.startswith("cond_enc.")}, max_model_len=200,
+                   max_num_seqs=2, cfg_scale=0.5)
+    want = eng.generate([{"prompt_token_ids": ro.prompt_token_ids, "multi_modal_data": {"conditionals": [cond]}} for ro in ros],
+                        SamplingParams(temperature=0.0, repetition_penalty=2.0, max_tokens=len(ros[0].outputs[0].token_ids),
+                                       stop_token_ids=[STOP_OFFSET_ID]))
+    eng.shutdown()
+    assert [w.outputs[0].token_ids for w in want] == [ro.outputs[0].token_ids for ro in ros]
+    assert all(torch.equal(o, postprocess_speech_ids(ro.outputs[0].token_ids, ro.prompt)) for o, ro in zip(out, ros))

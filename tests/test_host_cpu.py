@@ -218,3 +218,52 @@ def test_bench_starts_its_own_ranks_from_a_plain_shell():
                        capture_output=True, text=True, timeout=120, cwd=root,
                        env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
     assert p.returncode == 0 and json.loads(p.stdout.strip().splitlines()[-1])["ranks_seen"] == 1
+
+
+def _write_checkpoint_dir(d, golden_dir, n_layers=1):
+    """A checkpoint directory of the shape ChatterboxTTS.from_local reads (reference: tts.py:91-158): the T3
+    safetensors file (seeded synthetic values), tokenizer.json (a tiny BPE vocabulary made for these tests) and
+    conds.pt (tensors only)."""
+    import shutil
+    from safetensors.torch import save_file
+    cfg = T3ModelConfig.english(n_layers=n_layers)
+    sd = W.synthetic_state_dict(cfg)
+    sd.update({k: v for k, v in CE.synthetic_weights(1234).items()})
+    sd["text_head.weight"] = torch.zeros(704, 1024, dtype=torch.bfloat16)        # present in real checkpoints, skipped
+    save_file({k: v.contiguous() for k, v in sd.items()}, os.path.join(d, "t3_cfg.safetensors"))
+    shutil.copy(os.path.join(golden_dir, "tiny_tokenizer.json"), os.path.join(d, "tokenizer.json"))
+    torch.save({"t3": {"speaker_emb": torch.zeros(1, 256), "cond_prompt_speech_tokens": torch.zeros(1, 150, dtype=torch.long),
+                       "emotion_adv": 0.5 * torch.ones(1, 1, 1)}, "gen": {}}, os.path.join(d, "conds.pt"))
+    return cfg, sd
+
+
+def test_from_local_reads_a_checkpoint_directory(tmp_path, golden_dir, monkeypatch):
+    """ChatterboxTTS.from_local on a directory: safetensors load, tokenizer lookup in that directory, weights-only
+    load of conds.pt, the layer count taken from the checkpoint, kwargs passed through to the engine.  The engine
+    class is replaced by a recorder here (no GPU on this machine); tests/test_facade_gpu.py runs the same directory
+    through the real engine."""
+    from chatterbox_vllm_amd import tts as T
+    cfg, sd = _write_checkpoint_dir(str(tmp_path), golden_dir, n_layers=1)
+    seen = {}
+
+    class Recorder:
+        def __init__(self, model_config, state_dict, tokenizer=None, **kw):
+            seen.update(cfg=model_config, sd=state_dict, tok=tokenizer, kw=kw)
+            self.device = 0
+    monkeypatch.setattr(T, "T3Engine", Recorder)
+    m = T.ChatterboxTTS.from_local(str(tmp_path), max_model_len=300, max_batch_size=3, compile=True,
+                                   gpu_memory_utilization=0.4, scheduling_policy="fcfs")
+    assert seen["cfg"].n_layers == 1 and seen["cfg"].text_vocab == 704
+    assert torch.equal(seen["sd"]["speech_head.weight"], sd["speech_head.weight"]) and "text_head.weight" in seen["sd"]
+    assert seen["kw"]["max_model_len"] == 300 and seen["kw"]["max_num_seqs"] == 3 and seen["kw"]["scheduling_policy"] == "fcfs"
+    assert "gpu_memory_utilization" not in seen["kw"]
+    assert seen["tok"]("[START]Hi there.[STOP]") == [255, 36, 11, 2, 62, 20, 7, 55, 0]
+    assert m.default_conds is not None and m.default_conds["t3"]["speaker_emb"].shape == (1, 256)
+    assert m.cond_enc_weights is not None and "spkr_enc.weight" in m.cond_enc_weights
+    assert m.sr == 24000 and m.max_model_len == 300
+    with pytest.raises(FileNotFoundError):
+        T.ChatterboxTTS.from_local(str(tmp_path / "nowhere"))
+    os.remove(os.path.join(str(tmp_path), "tokenizer.json"))
+    monkeypatch.chdir(tmp_path)
+    with pytest.raises(FileNotFoundError):
+        T.ChatterboxTTS.from_local(str(tmp_path))

@@ -197,3 +197,39 @@ def test_oracle_reproduces_its_committed_golden_outputs():
                 assert (got - want).abs().max().item() <= tol, f"{mode} step {t}"
                 if margin > 2 * tol:
                     assert r["picks"][t] == tok, f"{mode} step {t}: decisive step changed its pick"
+
+
+def test_oracle_reproduces_its_decisive_goldens():
+    """The decisive cases of oracle_golden.json (checkpoint: weights.decisive_state_dict): a free-running oracle gives
+    the committed ids exactly -- every request and mode of the 2-layer case, the first 12 tokens of the first request
+    of the 30-layer case (the CPU suite's time budget) -- and every committed step is decisive by tests/parity_bar.py."""
+    import json, os
+    import parity_bar as PB
+    from chatterbox_vllm_amd.config import T3ModelConfig
+    from chatterbox_vllm_amd import weights as W
+    from oracle.t3_oracle import T3Oracle, SamplingSpec, build_prompt_ids
+    with open(os.path.join(os.path.dirname(__file__), "golden", "oracle_golden.json")) as f:
+        allgold = json.load(f)
+    for case, n_req, n_tok in (("decisive_micro", None, None), ("decisive_full", 1, 12)):
+        gold = allgold[case]
+        L = gold["n_layers"]
+        sd = W.decisive_state_dict(T3ModelConfig.english(n_layers=L))
+        long_ones = sum(min(len(m["token_ids"]) for m in r["modes"].values()) >= 64 for r in gold["requests"])
+        assert long_ones >= 4
+        for req in gold["requests"]:
+            assert build_prompt_ids(req["text_ids"]) == req["prompt_ids"]
+            for mode, g in req["modes"].items():
+                paired = mode != "single_stream"
+                tol = PB.logit_tol(gold["cfg_scale"] if paired else 0.0, L)
+                assert all(m > PB.decisive_margin(t, tol) for m, t in zip(g["margins"], g["top_logit"]))
+        for req in gold["requests"][:n_req]:
+            for mode, g in req["modes"].items():
+                paired = mode != "single_stream"
+                o = T3Oracle(sd, n_layers=L, cfg_scale=gold["cfg_scale"] if paired else 0.0,
+                             uncond_attends=mode != "paired_uncond_no_attention")
+                n = n_tok or gold["max_tokens"]
+                r = o.generate_one(req["text_ids"], W.synthetic_cond_emb(req["voice"]), SamplingSpec(max_tokens=n),
+                                   max_model_len=gold["max_model_len"], paired=paired)
+                assert r["token_ids"] == g["token_ids"][:n], f"{case} {mode}"
+                if n_tok is None:
+                    assert r["finish_reason"] == g["finish_reason"]

@@ -23,7 +23,7 @@ the whole sequence.
 
 Every case is run under the three semantics of the uncond stream (own KV / no attention / CFG off).  Per request
 and mode: the prompt ids, the greedy ids (+1000 space), the finish reason, per step the top-2 margin of the penalised
-logits, the top logit, and the first 8 speech logits.
+logits, the top logit, the first 8 speech logits and (decisive cases) the larger head-row scale of the top-2 columns.
 """
 import json
 import os
@@ -54,10 +54,11 @@ def text(n, seed):
     return [255] + torch.randint(3, 704, (n,), generator=g).tolist() + [0]
 
 
-def record(r):
+def record(r, row_scale=None):
     L = r["logits"]
-    top2 = torch.topk(L, 2, dim=-1).values
-    return {"token_ids": r["token_ids"], "finish_reason": r["finish_reason"],
+    top2, idx = torch.topk(L, 2, dim=-1)
+    rec = {} if row_scale is None else {"top2_row_scale": [round(float(row_scale[i].max()), 4) for i in idx]}
+    return {**rec, "token_ids": r["token_ids"], "finish_reason": r["finish_reason"],
             "margins": [round(float(a - b), 6) for a, b in top2],
             "top_logit": [round(float(a), 6) for a, _ in top2],
             "logits_1000_1008": [[round(float(x), 6) for x in row[1000:1008]] for row in L]}
@@ -78,15 +79,15 @@ def case(n_layers, texts, voices):
     return out
 
 
-def all_decisive(r, tol):
-    top2 = torch.topk(r["logits"], 2, dim=-1).values
-    return all(float(a - b) > PB.decisive_margin(float(a), tol) for a, b in top2)
+def all_decisive(r, tol, row_scale):
+    return all(PB.step_is_decisive(row, tol, row_scale) for row in r["logits"])
 
 
 def decisive_case(n_layers, want=4, max_candidates=400):
     """Search seeded candidates for requests whose every step is decisive in every mode."""
     cfg = T3ModelConfig.english(n_layers=n_layers)
     sd = W.decisive_state_dict(cfg)
+    row_scale = PB.head_row_scale(sd)
     oracles = {mode: T3Oracle(sd, n_layers=n_layers, cfg_scale=CFG_SCALE if paired else 0.0, **kw)
                for mode, kw, paired in MODES}
     tols = {mode: PB.logit_tol(CFG_SCALE if paired else 0.0, n_layers) for mode, _, paired in MODES}
@@ -108,7 +109,7 @@ def decisive_case(n_layers, want=4, max_candidates=400):
         for mode, _, paired in MODES:
             r = oracles[mode].generate_one(t, cond, SamplingSpec(max_tokens=1), max_model_len=256, paired=paired,
                                            return_logits=True)
-            if not all_decisive(r, tols[mode]) or r["token_ids"][0] in first_tokens:
+            if not all_decisive(r, tols[mode], row_scale) or r["token_ids"][0] in first_tokens:
                 ok = False
                 break
         if not ok:
@@ -118,10 +119,10 @@ def decisive_case(n_layers, want=4, max_candidates=400):
         for mode, _, paired in MODES:
             r = oracles[mode].generate_one(t, cond, SamplingSpec(max_tokens=DEC_TOK), max_model_len=256, paired=paired,
                                            return_logits=True)
-            if not all_decisive(r, tols[mode]):
+            if not all_decisive(r, tols[mode], row_scale):
                 ok = False
                 break
-            rec["modes"][mode] = record(r)
+            rec["modes"][mode] = record(r, row_scale)
         if not ok:
             continue
         lens = [len(m["token_ids"]) for m in rec["modes"].values()]

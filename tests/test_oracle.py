@@ -221,7 +221,7 @@ def test_oracle_reproduces_its_decisive_goldens():
             for mode, g in req["modes"].items():
                 paired = mode != "single_stream"
                 tol = PB.logit_tol(gold["cfg_scale"] if paired else 0.0, L)
-                assert all(m > PB.decisive_margin(t, tol) for m, t in zip(g["margins"], g["top_logit"]))
+                assert all(m > PB.decisive_margin(t, tol, sc) for m, t, sc in zip(g["margins"], g["top_logit"], g["top2_row_scale"]))
         for req in gold["requests"][:n_req]:
             for mode, g in req["modes"].items():
                 paired = mode != "single_stream"

@@ -6,7 +6,7 @@
 For each checkpoint (flat = synthetic_state_dict, decisive = decisive_state_dict), layer count and CFG scale: three
 requests x 24 greedy tokens through the HIP engine with logit taps, the CPU oracle teacher-forced on the engine's ids,
 and over all finite penalised logits of all steps: quantiles of |engine - oracle|, its worst value, the worst value
-in units of the stated tolerance (tests/parity_bar.py: tol_at(logit, logit_tol(cfg_scale, L))), and the share of
+in units of the stated tolerance (tests/parity_bar.py: tol_at(logit, logit_tol(cfg_scale, L), head-row scale)), and the share of
 steps on which both picked the same id.  The tolerance's depth factor max(1, sqrt(L/8)) is checked against this file."""
 import json
 import os
@@ -49,16 +49,17 @@ def measure(kind, L, s):
     eng.shutdown()
     oracle = T3Oracle(sd, n_layers=L, cfg_scale=s)
     tol = PB.logit_tol(s, L)
+    row_scale = PB.head_row_scale(sd)
     errs, rel, same, steps, top_err = [], [], 0, 0, []
     for rid, t, v in zip(rids, texts, voices):
-        r = oracle.generate_one(t, W.synthetic_cond_emb(v), SamplingSpec(max_tokens=N_TOK), max_model_len=256,
+        r = oracle.generate_one(t, W.synthetic_cond_emb(v), SamplingSpec(max_tokens=N_TOK, stop_token_ids=()), max_model_len=256,
                                 forced=ids[rid], return_logits=True)
         for k, row in enumerate(logits[rid]):
             ref = r["logits"][k]
             fin = torch.isfinite(ref)
             d = (row[fin] - ref[fin]).abs()
             errs.append(d)
-            rel.append((d / PB.tol_at(ref[fin], tol)).max().item())
+            rel.append((d / PB.tol_at(ref[fin], tol, row_scale[fin])).max().item())
             top_err.append(abs(row[ids[rid][k]].item() - ref[ids[rid][k]].item()))
             same += int(ids[rid][k] == r["picks"][k])
             steps += 1

@@ -114,6 +114,7 @@ SIGNATURES = {
     "t3_op_attn_decode": ([_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, C.c_int64, C.c_int32, _P,
                            C.c_int32, _P], C.c_int),
     "t3_op_attn_prefill": ([_P, _P, C.c_int32, _P, _I32P, C.c_int32, C.c_int32, _P], C.c_int),
+    "t3_op_attn_prefill_static": ([_P, _P, C.c_int32, _P, _I32P, C.c_int32, C.c_int32, _P], C.c_int),
     "t3_op_attn_decode_prefix": ([_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, C.c_int64, C.c_int32, _P,
                                   C.c_int32, _P, C.c_int32, _P], C.c_int),
     "t3_op_attn_prefill_prefix": ([_P, _P, C.c_int32, _P, _I32P, C.c_int32, C.c_int32, _P, C.c_int32, _P, C.c_int64,

@@ -3,6 +3,7 @@
 #include "t3_common.h"
 #include "../../include/t3_hip.h"
 
+#include <mutex>
 #include <vector>
 
 static KvView make_kv(void* pool, int64_t layer_stride, const int32_t* bt, int32_t max_pages, int H, int hd) {
@@ -221,6 +222,74 @@ static int attn_prefill_op(const void* qkv_dev, void* out_dev, int32_t n_seqs, c
     if (rc) return rc;
     T3_HIP_CHECK(se);
     return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// t3_op_attn_prefill for callers that cannot allocate (code under HIP graph capture, serving loops or harnesses that
+// forbid hipMalloc).  attn_prefill_op above builds the (sequence, first query row) list of the launch's 64-query tiles
+// on the host and stages it through a hipMalloc'ed buffer; here the list is built by a one-workgroup kernel from
+// seq_start_dev straight into `scratch`, a file-scope device array every GPU holds its own copy of until the process
+// ends, and the attention kernel reads it from there.  Nothing is allocated, copied or synchronised.
+//
+// In host code the array's NAME is not a device address; the address of the current device's copy comes from
+// hipGetSymbolAddress, once per device, and only that pointer is handed to kernels.  Every call on a GPU uses that
+// GPU's one array: calls that overlap on one GPU (two streams, two threads) race on it.  Every entry a launch reads
+// has been written by the same call's build kernel, so nothing needs clearing between calls.
+// ------------------------------------------------------------------------------------------------------------------
+#define T3_STATIC_TILES_MAX 4096       // 64-query tiles per call (32 KiB of scratch); sum over sequences of ceil(rows / 64)
+#define T3_STATIC_SEQS_MAX 1024        // sequences per call
+static __device__ __align__(256) int32_t scratch[2 * T3_STATIC_TILES_MAX];
+
+__global__ __launch_bounds__(256) void build_prefill_tiles_kernel(const int32_t* __restrict__ seq_start, int n_seqs,
+                                                                  int32_t* __restrict__ tiles) {
+    __shared__ int32_t first_tile[T3_STATIC_SEQS_MAX + 1];
+    for (int i = threadIdx.x; i < n_seqs; i += 256) first_tile[i + 1] = (seq_start[i + 1] - seq_start[i] + 63) >> 6;
+    __syncthreads();
+    if (threadIdx.x == 0) {                              // exclusive prefix sum; n_seqs <= 1024
+        first_tile[0] = 0;
+        for (int i = 0; i < n_seqs; ++i) first_tile[i + 1] += first_tile[i];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_seqs; i += 256)
+        for (int t = first_tile[i], q0 = 0; t < first_tile[i + 1]; ++t, q0 += 64) { tiles[2 * t] = i; tiles[2 * t + 1] = q0; }
+}
+
+static int32_t* g_scratch_ptr[T3_MAX_DEVICES];           // address of `scratch` on each device, looked up on first use
+static std::mutex g_scratch_mutex;
+
+static int scratch_of_current_device(int32_t** out) {
+    int dev = -1;
+    T3_HIP_CHECK(hipGetDevice(&dev));
+    T3_REQUIRE(dev >= 0 && dev < T3_MAX_DEVICES, "device ordinal out of range");
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        void* p = nullptr;
+        T3_HIP_CHECK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));      // the copy of the device that is current now
+        T3_REQUIRE(p != nullptr, "hipGetSymbolAddress returned no address");
+        g_scratch_ptr[dev] = static_cast<int32_t*>(p);
+    }
+    *out = g_scratch_ptr[dev];
+    return 0;
+}
+
+extern "C" int t3_op_attn_prefill_static(const void* qkv_dev, void* out_dev, int32_t n_seqs, const int32_t* seq_start_dev,
+                                         const int32_t* seq_start_host, int32_t H, int32_t hd, void* stream) {
+    T3_REQUIRE(qkv_dev && out_dev && seq_start_dev && seq_start_host, "null argument");
+    T3_REQUIRE(n_seqs >= 1 && n_seqs <= T3_STATIC_SEQS_MAX, "attn_prefill_static: 1..1024 sequences per call");
+    int64_t ntiles = 0;
+    for (int i = 0; i < n_seqs; ++i) {
+        T3_REQUIRE(seq_start_host[i + 1] > seq_start_host[i], "empty sequence");
+        ntiles += (seq_start_host[i + 1] - seq_start_host[i] + 63) / 64;
+    }
+    T3_REQUIRE(ntiles <= T3_STATIC_TILES_MAX,
+               "attn_prefill_static: more than 4096 query tiles (sum of ceil(rows / 64)); use t3_op_attn_prefill");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int32_t* tiles = nullptr;
+    if (scratch_of_current_device(&tiles)) return 1;
+    T3_LAUNCH(build_prefill_tiles_kernel, dim3(1), dim3(256), 0, st, seq_start_dev, n_seqs, tiles);
+    T3_HIP_CHECK(hipGetLastError());
+    return launch_attn_prefill(static_cast<const bf16_t*>(qkv_dev), 3 * H * hd, static_cast<bf16_t*>(out_dev), seq_start_dev,
+                               tiles, (int)ntiles, H, hd, st, nullptr, 0, nullptr, 0);
 }
 
 extern "C" int t3_op_sample_greedy(const void* logits_dev, int32_t ldl, int32_t vocab, const int32_t* row_c_dev,

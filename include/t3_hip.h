@@ -262,6 +262,17 @@ int t3_op_attn_decode(const void* qkv_dev, void* out_dev, int32_t rows, int32_t 
 /* Causal attention inside packed prompt rows: sequence i owns rows [seq_start[i], seq_start[i+1]). */
 int t3_op_attn_prefill(const void* qkv_dev, void* out_dev, int32_t n_seqs, const int32_t* seq_start_dev,
                        const int32_t* seq_start_host, int32_t H, int32_t hd, void* stream);
+/* t3_op_attn_prefill for callers that cannot allocate: code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc.  It has no counterpart in the reference (whose attention runs inside the vLLM wheel).
+ * Same arguments and bit-identical output; the list of query tiles, which t3_op_attn_prefill stages through a buffer
+ * it allocates, is built on the device into a 32 KiB array inside the library's code object, so the call allocates
+ * nothing, copies nothing and does not synchronise: both kernels are only enqueued on `stream`.
+ * Limits: at most 1024 sequences and 4096 query tiles (sum over sequences of ceil(rows / 64)) per call; larger calls
+ * are refused with an error.  Every GPU holds one such array for the life of the process, every call on that GPU uses
+ * it: calls that overlap on one GPU race.  Make the first call on a device outside any graph capture (it looks the
+ * array's address up once per device). */
+int t3_op_attn_prefill_static(const void* qkv_dev, void* out_dev, int32_t n_seqs, const int32_t* seq_start_dev,
+                              const int32_t* seq_start_host, int32_t H, int32_t hd, void* stream);
 /* The two attention forms with a shared prefix (the engine's prefix_sharing mode; no counterpart in the reference,
  * which keeps vLLM's prefix cache from matching, models/t3/t3.py:286-289).
  * Decode: where prefix_page_dev[r] >= 0, positions [0, n_prefix) of row r are read from that page of the pool

@@ -11,7 +11,7 @@ import os
 from functools import lru_cache
 
 LIB_NAME = "libt3hip.so"
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class T3Error(RuntimeError):
@@ -63,6 +63,7 @@ class T3GemmDesc(C.Structure):
         ("a_tiled", C.c_int32), ("out_tiled", C.c_int32),
         ("fn_slab_dev", C.c_void_p), ("fn_res_in_dev", C.c_void_p), ("fn_res_out_dev", C.c_void_p),
         ("fn_norm_w_dev", C.c_void_p), ("fn_nsplit", C.c_int32), ("fn_eps", C.c_float),
+        ("fn_pair_scale_dev", C.c_void_p),
     ]
 
 
@@ -113,6 +114,10 @@ SIGNATURES = {
     "t3_op_gemm_ex": ([C.POINTER(T3GemmDesc), _P], C.c_int),
     "t3_op_attn_decode": ([_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, C.c_int64, C.c_int32, _P,
                            C.c_int32, _P], C.c_int),
+    "t3_op_attn_decode_oproj": ([_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, C.c_int64, C.c_int32, _P,
+                                 C.c_int32, _P, C.c_int32, C.c_int32, _P, C.c_int32, _P], C.c_int),
+    "t3_op_oproj_split": ([], C.c_int),
+    "t3_op_head_slab_add_rmsnorm": ([_P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_float, _P], C.c_int),
     "t3_op_attn_prefill": ([_P, _P, C.c_int32, _P, _I32P, C.c_int32, C.c_int32, _P], C.c_int),
     "t3_op_attn_prefill_static": ([_P, _P, C.c_int32, _P, _I32P, C.c_int32, C.c_int32, _P], C.c_int),
     "t3_op_attn_decode_prefix": ([_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, C.c_int64, C.c_int32, _P,

@@ -26,108 +26,104 @@
 // tile -> wave -> merge order depends only on the row's own context length, never on the
 // batch, so results are bit-identical for any batch composition.
 //
+// Output projection in the same launch (OPROJ; the engine keeps it OFF, T3_FUSED_OPROJ=1 turns it on): the 64 values a
+// workgroup ends with are exactly the K range of o_proj that belongs to its head, so the workgroup can multiply them
+// (rounded to bf16, as the attention output is) with Wo[:, 64h .. 64h+64) itself and write the fp32 partial sums to
+// slab[h][row][0..1024): o_proj as a split-K over the 16 heads, one dependent launch fewer per layer.  The fold adds
+// heads 2s and 2s+1 and then the eight pair sums in order: the additions of the stand-alone projection's eight split-K
+// slabs, so both forms give the same bits (int8 column scales are applied by the fold).  The weight tiles (128 KiB per
+// head, the tile order of gemm.hip; all rows of a head run on one XCD) feed 16 MFMAs per wave with the group's rows in
+// the first columns of the B operand.  Measured on the benchmark job (62 rows): the attention launch is bound by what a
+// CU's vector memory path moves, and every extra byte through it, L2 hits included, costs what a K/V byte costs:
+// one workgroup per (head, row) re-reads 127 MB of Wo per launch, 21.2 -> 26.6 us; four rows per workgroup (one
+// workgroup per CU, two tiles in flight per wave) 26.5 us, two rows 25.4 us, against 21.6 + 4.4 us for the two launches;
+// with one row (single stream) 16 workgroups cannot pull Wo at the chip's rate: 1287 against 1333 tokens/s.
+//
 // Shared prefix: when row_pfx[r] >= 0, positions [0, npfx) of row r live in page row_pfx[r]
 // (one copy for every stream that starts with the same conditioning rows) and the row's own
 // page 0 holds only positions [npfx, 64).  The tile boundaries stay where they are, each lane
 // just picks the page its token is in, so the result has the same bits as with private
 // copies, and all rows of a step read the same few KiB, which then come from L2.
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(ATT_NW * 64) void attn_decode_kernel(
-        const bf16_t* __restrict__ qkv, int ldq, bf16_t* __restrict__ out, int ldo,
-        const int32_t* __restrict__ row_stream, const int32_t* __restrict__ row_ctx, KvView kv, int layer,
-        const int32_t* __restrict__ row_pfx, int npfx
-#ifdef T3_ATTN_TIMELINE
-        , long long* ts
-#endif
-        ) {
-#ifdef T3_ATTN_TIMELINE
-#define ATT_STAMP(i) do { if ((threadIdx.x & 63) == 0) ts[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * ATT_NW + (threadIdx.x >> 6)) * 8 + (i)] = wall_clock64(); } while (0)
-#else
-#define ATT_STAMP(i) do { } while (0)
-#endif
-    ATT_STAMP(0);
-    __shared__ float part[ATT_NW][8][12];
-    const int h = blockIdx.x, r = blockIdx.y;
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int c = lane & 7, tg = lane >> 3;
-    const int st = row_stream[r];
-    const int ctx = row_ctx[r];
-    const int pfx = row_pfx ? row_pfx[r] : -1;
-    const int hd = 64;
-
-    float q[8];
-    {
-        const u32x4 qv = *reinterpret_cast<const u32x4*>(qkv + (size_t)r * ldq + h * hd + c * 8);
+// 8 offset-binary bytes (two dwords) -> 8 bf16 values u - 128 (int8 weights, as in gemm.hip)
+__device__ __forceinline__ bf16x8 att_dequant8(unsigned lo, unsigned hi) {
+    bf16x8 r;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { q[2 * i] = bf_lo(qv[i]); q[2 * i + 1] = bf_hi(qv[i]); }
+    for (int j = 0; j < 4; ++j) {
+        r[j] = (__bf16)((float)((lo >> (8 * j)) & 0xffu) - 128.0f);
+        r[4 + j] = (__bf16)((float)((hi >> (8 * j)) & 0xffu) - 128.0f);
     }
-    float m = -1e30f, l = 0.f, o[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = 0.f;
+    return r;
+}
 
-    const int ntiles = st >= 0 ? (ctx + 63) >> 6 : 0;
-    const size_t slab = (size_t)T3_PAGE * hd;                      // one (page, kv, head) slab
-    const bf16_t* lbase = kv.pool + (size_t)layer * kv.layer_stride;
-    for (int tile = w; tile < ntiles; tile += ATT_NW) {
-        const int page = kv.block_table[(size_t)st * kv.max_pages + tile];
-        const bf16_t* kb = lbase + ((size_t)page * 2 * kv.H + h) * slab + lane * 8;
-        // lanes whose token lies in the shared prefix read the prefix page (tile 0 only): an element
-        // offset between the two pages, zero everywhere else
-        const bool shared = tile == 0 && pfx >= 0;
-        const long long to_pfx = shared ? ((long long)pfx - page) * (long long)(2 * kv.H) * (long long)slab : 0;
-        const int lim = shared ? npfx : 0;
-        const size_t vofs = (size_t)kv.H * slab;
-        u32x4 kr[8], vr[8];
-        if (tile == w) ATT_STAMP(1);
+// One 64-token tile of one (row, head) in a wave's registers: 8 K and 8 V pieces of 16 bytes per lane.
+struct AttTile { u32x4 k[8], v[8]; };
+
+// Requests the tile's 16 loads.  Lanes whose token lies in the shared prefix read the prefix page (tile 0 only): an
+// element offset between the two pages, zero everywhere else.
+__device__ __forceinline__ void att_load_tile(AttTile& t, const bf16_t* __restrict__ lbase, const KvView& kv, int st, int tile,
+                                              int h, int lane, int pfx, int npfx) {
+    const int tg = lane >> 3;
+    const size_t slab = (size_t)T3_PAGE * 64;                      // one (page, kv, head) slab
+    const int page = kv.block_table[(size_t)st * kv.max_pages + tile];
+    const bf16_t* kb = lbase + ((size_t)page * 2 * kv.H + h) * slab + lane * 8;
+    const bool shared = tile == 0 && pfx >= 0;
+    const long long to_pfx = shared ? ((long long)pfx - page) * (long long)(2 * kv.H) * (long long)slab : 0;
+    const int lim = shared ? npfx : 0;
+    const size_t vofs = (size_t)kv.H * slab;
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const bf16_t* p = kb + it * 512 + (it * 8 + tg < lim ? to_pfx : 0);
-            kr[it] = ATT_LOAD(reinterpret_cast<const u32x4*>(p));
-        }
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const bf16_t* p = kb + vofs + it * 512 + (it * 8 + tg < lim ? to_pfx : 0);
-            vr[it] = ATT_LOAD(reinterpret_cast<const u32x4*>(p));
-        }
-        float s[8];
-        float mt = m;
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            float d = 0.f;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                d = fmaf(q[2 * i], bf_lo(kr[it][i]), d);
-                d = fmaf(q[2 * i + 1], bf_hi(kr[it][i]), d);
-            }
-            d += __shfl_xor(d, 1);
-            d += __shfl_xor(d, 2);
-            d += __shfl_xor(d, 4);
-            s[it] = d * 0.125f;
-            const bool valid = tile * 64 + it * 8 + tg < ctx;
-            s[it] = valid ? s[it] : -1e30f;
-            mt = fmaxf(mt, s[it]);
-        }
-        const float alpha = __expf(m - mt);
-        l *= alpha;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] *= alpha;
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const bool valid = tile * 64 + it * 8 + tg < ctx;
-            const float p = valid ? __expf(s[it] - mt) : 0.f;
-            l += p;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                o[2 * i] = fmaf(p, bf_lo(vr[it][i]), o[2 * i]);
-                o[2 * i + 1] = fmaf(p, bf_hi(vr[it][i]), o[2 * i + 1]);
-            }
-        }
-        m = mt;
-        if (tile == w) ATT_STAMP(2);
+    for (int it = 0; it < 8; ++it) {
+        const bf16_t* p = kb + it * 512 + (it * 8 + tg < lim ? to_pfx : 0);
+        t.k[it] = ATT_LOAD(reinterpret_cast<const u32x4*>(p));
     }
-    ATT_STAMP(3);
-    // merge the 8 token groups of the wave
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const bf16_t* p = kb + vofs + it * 512 + (it * 8 + tg < lim ? to_pfx : 0);
+        t.v[it] = ATT_LOAD(reinterpret_cast<const u32x4*>(p));
+    }
+}
+
+// Folds the tile into the lane group's online-softmax state (m, l, o[8]).
+__device__ __forceinline__ void att_fold_tile(const AttTile& t, const float (&q)[8], int tile, int ctx, int tg, float& m, float& l,
+                                              float (&o)[8]) {
+    float s[8];
+    float mt = m;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        float d = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            d = fmaf(q[2 * i], bf_lo(t.k[it][i]), d);
+            d = fmaf(q[2 * i + 1], bf_hi(t.k[it][i]), d);
+        }
+        d += __shfl_xor(d, 1);
+        d += __shfl_xor(d, 2);
+        d += __shfl_xor(d, 4);
+        s[it] = d * 0.125f;
+        const bool valid = tile * 64 + it * 8 + tg < ctx;
+        s[it] = valid ? s[it] : -1e30f;
+        mt = fmaxf(mt, s[it]);
+    }
+    const float alpha = __expf(m - mt);
+    l *= alpha;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] *= alpha;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const bool valid = tile * 64 + it * 8 + tg < ctx;
+        const float p = valid ? __expf(s[it] - mt) : 0.f;
+        l += p;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            o[2 * i] = fmaf(p, bf_lo(t.v[it][i]), o[2 * i]);
+            o[2 * i + 1] = fmaf(p, bf_hi(t.v[it][i]), o[2 * i + 1]);
+        }
+    }
+    m = mt;
+}
+
+// Merges the 8 token groups of the wave (butterflies over lane bits 3..5).
+__device__ __forceinline__ void att_merge_groups(float& m, float& l, float (&o)[8]) {
 #pragma unroll
     for (int off = 8; off < 64; off <<= 1) {
         const float m2 = __shfl_xor(m, off), l2 = __shfl_xor(l, off);
@@ -138,30 +134,160 @@ __global__ __launch_bounds__(ATT_NW * 64) void attn_decode_kernel(
         for (int j = 0; j < 8; ++j) o[j] = o[j] * a1 + __shfl_xor(o[j], off) * a2;
         m = mn;
     }
-    if (tg == 0) {
-        part[w][c][0] = m; part[w][c][1] = l;
+}
+
+// RPW rows per workgroup.  RPW = 1: workgroup = (head, row), two workgroups per CU (second launch bound: 4 waves per SIMD, at
+// most 128 VGPRs).  RPW = 4 (full decode steps, with OPROJ): workgroup = (head, group of 4 rows); wave w takes tile w (w + 8,
+// ...) of EVERY row of the group, one row after the other, exactly as it would in four workgroups of its own, so a row's bits
+// do not depend on the grouping; the first tile of the next row is requested before the current row's tile is folded (two tile
+// buffers, so every wave keeps two tiles in flight), one workgroup per CU (256 VGPRs), and the head's 128 KiB of Wo are read
+// once per four rows.  The host orders the rows so that the groups hold about the same number of positions.
+template <int RPW, bool OPROJ, bool W8>
+__global__ __launch_bounds__(ATT_NW * 64, (RPW > 2 || (OPROJ && RPW == 1)) ? 2 : 4) void attn_decode_kernel(
+        const bf16_t* __restrict__ qkv, int ldq, bf16_t* __restrict__ out, int ldo, int rows,
+        const int32_t* __restrict__ row_stream, const int32_t* __restrict__ row_ctx, KvView kv, int layer,
+        const int32_t* __restrict__ row_pfx, int npfx,
+        const bf16_t* __restrict__ wo, float* __restrict__ oslab
+#ifdef T3_ATTN_TIMELINE
+        , long long* ts
+#endif
+        ) {
+#ifdef T3_ATTN_TIMELINE
+#define ATT_STAMP(i) do { if ((threadIdx.x & 63) == 0) ts[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * ATT_NW + (threadIdx.x >> 6)) * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define ATT_STAMP(i) do { } while (0)
+#endif
+    ATT_STAMP(0);
+    __shared__ float part[RPW][ATT_NW][8][12];
+    __shared__ __attribute__((aligned(16))) bf16_t o_sh[RPW][64];
+    const int h = blockIdx.x, r0 = blockIdx.y * RPW;
+    const int nr = rows - r0 < RPW ? rows - r0 : RPW;              // rows of this group
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 7, tg = lane >> 3;
+    const int hd = 64;
+    const bf16_t* lbase = kv.pool + (size_t)layer * kv.layer_stride;
+
+    int st[RPW], ctx[RPW], pfx[RPW], nt[RPW];
+    float q[RPW][8], m[RPW], l[RPW], o[RPW][8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) part[w][c][2 + j] = o[j];
+    for (int i = 0; i < RPW; ++i) {
+        const int r = r0 + (i < nr ? i : 0);
+        st[i] = row_stream[r];
+        ctx[i] = row_ctx[r];
+        pfx[i] = row_pfx ? row_pfx[r] : -1;
+        nt[i] = (i < nr && st[i] >= 0) ? (ctx[i] + 63) >> 6 : 0;
+        const u32x4 qv = *reinterpret_cast<const u32x4*>(qkv + (size_t)r * ldq + h * hd + c * 8);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { q[i][2 * k] = bf_lo(qv[k]); q[i][2 * k + 1] = bf_hi(qv[k]); }
+        m[i] = -1e30f; l[i] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[i][k] = 0.f;
+    }
+
+    // OPROJ, one row per workgroup (launches of a few rows): the weight tiles are requested before the K/V stream
+    constexpr int OP_NB = 1024 / 16 / ATT_NW;              // column blocks per wave
+    static_assert(!OPROJ || (ATT_NW == 8 && OP_NB == 8), "the output projection is laid out for 8 waves x 8 column blocks");
+    bf16x8 wt[OPROJ && !W8 ? OP_NB : 1][2];
+    u32x4 wq[OPROJ && W8 ? OP_NB : 1];
+    auto load_wo = [&]() {
+#pragma unroll
+        for (int i = 0; i < OP_NB; ++i) {
+            const int nb = w * OP_NB + i;
+            if constexpr (W8) {
+                wq[i] = *(reinterpret_cast<const u32x4*>(wo) + ((size_t)nb * 16 + h) * 64 + lane);
+            } else {
+                const bf16x8* wp = reinterpret_cast<const bf16x8*>(wo) + ((size_t)nb * 32 + 2 * h) * 64 + lane;
+                wt[i][0] = wp[0];
+                wt[i][1] = wp[64];
+            }
+        }
+    };
+    if constexpr (OPROJ && RPW == 1) load_wo();
+
+    constexpr bool DBUF = RPW > 2;                         // two tile buffers: the next row's first tile is requested ahead
+    AttTile buf[DBUF ? 2 : 1];
+    ATT_STAMP(1);
+    if (w < nt[0]) att_load_tile(buf[0], lbase, kv, st[0], w, h, lane, pfx[0], npfx);
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        if constexpr (DBUF) {
+            if (i + 1 < RPW) {
+                if (w < nt[i + 1 < RPW ? i + 1 : 0])
+                    att_load_tile(buf[(i + 1) & 1], lbase, kv, st[i + 1 < RPW ? i + 1 : 0], w, h, lane, pfx[i + 1 < RPW ? i + 1 : 0], npfx);
+            }
+        }
+        AttTile& cur = buf[DBUF ? (i & 1) : 0];
+        if constexpr (!DBUF) { if (i > 0 && w < nt[i]) att_load_tile(cur, lbase, kv, st[i], w, h, lane, pfx[i], npfx); }
+        if (w < nt[i]) att_fold_tile(cur, q[i], w, ctx[i], tg, m[i], l[i], o[i]);
+        for (int tile = w + ATT_NW; tile < nt[i]; tile += ATT_NW) {      // contexts beyond 512 positions
+            att_load_tile(cur, lbase, kv, st[i], tile, h, lane, pfx[i], npfx);
+            att_fold_tile(cur, q[i], tile, ctx[i], tg, m[i], l[i], o[i]);
+        }
+    }
+    ATT_STAMP(2);
+    // OPROJ, grouped rows: this wave's 16 weight tiles of Wo (output columns 128w .. 128w+128 x the head's 64 inputs),
+    // requested now (the tile buffers are free), used after the merge.  bf16: tile (nb, kb) of 1 KiB, kb = 2h, 2h+1; int8:
+    // one pair tile per nb holds both.  All rows of a head run on one XCD, so after the first group they come from its L2.
+    if constexpr (OPROJ && RPW > 1) load_wo();
+    ATT_STAMP(3);
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        att_merge_groups(m[i], l[i], o[i]);
+        if (tg == 0) {
+            part[i][w][c][0] = m[i]; part[i][w][c][1] = l[i];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) part[i][w][c][2 + j] = o[i][j];
+        }
     }
     __syncthreads();
-    if (threadIdx.x < 8) {
-        float M = part[0][c][0], L = part[0][c][1], O[8];
+    if (threadIdx.x < 8 * RPW) {
+        const int i = threadIdx.x >> 3;                     // row of the group; c = threadIdx.x & 7
+        float M = part[i][0][c][0], L = part[i][0][c][1], O[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) O[j] = part[0][c][2 + j];
+        for (int j = 0; j < 8; ++j) O[j] = part[i][0][c][2 + j];
         for (int w2 = 1; w2 < ATT_NW; ++w2) {
-            const float m2 = part[w2][c][0], l2 = part[w2][c][1];
+            const float m2 = part[i][w2][c][0], l2 = part[i][w2][c][1];
             const float mn = fmaxf(M, m2);
             const float a1 = __expf(M - mn), a2 = __expf(m2 - mn);
             L = L * a1 + l2 * a2;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) O[j] = O[j] * a1 + part[w2][c][2 + j] * a2;
+            for (int j = 0; j < 8; ++j) O[j] = O[j] * a1 + part[i][w2][c][2 + j] * a2;
             M = mn;
         }
         const float inv = L > 0.f ? 1.0f / L : 0.f;
         u32x4 ov;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ov[i] = pack_bf2(O[2 * i] * inv, O[2 * i + 1] * inv);
-        *reinterpret_cast<u32x4*>(out + (size_t)r * ldo + h * hd + c * 8) = ov;
+        for (int k = 0; k < 4; ++k) ov[k] = pack_bf2(O[2 * k] * inv, O[2 * k + 1] * inv);
+        if constexpr (OPROJ) *reinterpret_cast<u32x4*>(&o_sh[i][c * 8]) = ov;
+        else if (i < nr) *reinterpret_cast<u32x4*>(out + (size_t)(r0 + i) * ldo + h * hd + c * 8) = ov;
+    }
+    if constexpr (OPROJ) {
+        __syncthreads();
+        // B operand of D = Wtile(16 n x 32 k) * B(32 k x 16 columns): row i of the group sits in column i, the rest is zero
+        const int col = lane & 15;
+        const bool live = col < nr;
+        bf16x8 bfrag[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            u32x4 v = *reinterpret_cast<const u32x4*>(&o_sh[live ? col : 0][32 * kt + 8 * (lane >> 4)]);
+            if (!live) v = u32x4{0u, 0u, 0u, 0u};
+            bfrag[kt] = __builtin_bit_cast(bf16x8, v);
+        }
+        float* srow = oslab + ((size_t)h * rows + r0 + (live ? col : 0)) * 1024 + 4 * (lane >> 4);
+#pragma unroll
+        for (int i = 0; i < OP_NB; ++i) {
+            const int nb = w * OP_NB + i;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (W8) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_dequant8(wq[i][0], wq[i][1]), bfrag[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_dequant8(wq[i][2], wq[i][3]), bfrag[1], acc, 0, 0, 0);
+            } else {
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wt[i][0], bfrag[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wt[i][1], bfrag[1], acc, 0, 0, 0);
+            }
+            if (live) *reinterpret_cast<f32x4*>(srow + nb * 16) = acc;
+        }
     }
     ATT_STAMP(4);
 }
@@ -173,8 +299,31 @@ int launch_attn_decode(const bf16_t* qkv, int ldq, bf16_t* out, int rows, const 
     T3_REQUIRE(kv.hd == 64, "attn_decode: head_dim must be 64");
     T3_REQUIRE(rows >= 1 && ldq % 8 == 0, "attn_decode: bad shape");
     T3_REQUIRE(row_pfx == nullptr || (npfx >= 1 && npfx <= T3_PAGE), "attn_decode: the shared prefix must fit one page");
-    T3_LAUNCH(attn_decode_kernel, dim3(kv.H, rows), dim3(ATT_NW * 64), 0, st, qkv, ldq, out,
-                       kv.H * kv.hd, row_stream, row_ctx, kv, layer, row_pfx, npfx);
+    T3_LAUNCH((attn_decode_kernel<1, false, false>), dim3(kv.H, rows), dim3(ATT_NW * 64), 0, st, qkv, ldq, out,
+              kv.H * kv.hd, rows, row_stream, row_ctx, kv, layer, row_pfx, npfx, static_cast<const bf16_t*>(nullptr),
+              static_cast<float*>(nullptr));
+    T3_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// Attention + output projection: slab[h][row][0..1024) = bf16(attention of head h) x Wq[:, 64h..64h+64)^T, fp32, where Wq is
+// Wo in the tile order of gemm.hip (bf16 tiles), or its unscaled int8 values (pair tiles; `int8` set: the fold applies the
+// column scales).  rows_per_group: 1 (workgroup = (head, row)) or ATTN_GROUP_ROWS (workgroup = (head, 4 consecutive rows)).
+int launch_attn_decode_oproj(const bf16_t* qkv, int ldq, float* slab, int rows, const int32_t* row_stream,
+                             const int32_t* row_ctx, const KvView& kv, int layer, const bf16_t* wo, bool int8,
+                             int rows_per_group, hipStream_t st, const int32_t* row_pfx, int npfx) {
+    T3_REQUIRE(kv.hd == 64 && kv.H == 16, "attn_decode_oproj: built for 16 heads x 64");
+    T3_REQUIRE(rows >= 1 && ldq % 8 == 0 && slab && wo, "attn_decode_oproj: bad arguments");
+    T3_REQUIRE(rows_per_group == 1 || rows_per_group == 2 || rows_per_group == 4, "attn_decode_oproj: rows per group must be 1, 2 or 4");
+    T3_REQUIRE(row_pfx == nullptr || (npfx >= 1 && npfx <= T3_PAGE), "attn_decode: the shared prefix must fit one page");
+    const int groups = (rows + rows_per_group - 1) / rows_per_group;
+#define T3_ATT_OPROJ(RPW, W8)                                                                                              \
+    T3_LAUNCH((attn_decode_kernel<RPW, true, W8>), dim3(kv.H, groups), dim3(ATT_NW * 64), 0, st, qkv, ldq,                \
+              static_cast<bf16_t*>(nullptr), 0, rows, row_stream, row_ctx, kv, layer, row_pfx, npfx, wo, slab)
+    if (rows_per_group == 1) { if (int8) T3_ATT_OPROJ(1, true); else T3_ATT_OPROJ(1, false); }
+    else if (rows_per_group == 2) { if (int8) T3_ATT_OPROJ(2, true); else T3_ATT_OPROJ(2, false); }
+    else { if (int8) T3_ATT_OPROJ(4, true); else T3_ATT_OPROJ(4, false); }
+#undef T3_ATT_OPROJ
     T3_HIP_CHECK(hipGetLastError());
     return 0;
 }

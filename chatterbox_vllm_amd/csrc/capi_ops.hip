@@ -137,6 +137,7 @@ extern "C" int t3_op_gemm_ex(const t3_gemm_desc* d, void* stream) {
         g.fn_w = static_cast<const bf16_t*>(d->fn_norm_w_dev); g.fn_eps = d->fn_eps; g.fn_nsplit = d->fn_nsplit;
         g.fn_slab = d->fn_slab_dev; g.fn_res_in = static_cast<const bf16_t*>(d->fn_res_in_dev);
         g.fn_res_out = static_cast<bf16_t*>(d->fn_res_out_dev);
+        g.fn_pair_scale = d->fn_pair_scale_dev;
     }
     switch (d->epilogue) {
         case 0: case 1:
@@ -180,6 +181,28 @@ extern "C" int t3_op_attn_decode_prefix(const void* qkv_dev, void* out_dev, int3
     const KvView kv = make_kv(const_cast<void*>(kv_pool_dev), layer_stride_elems, block_table_dev, max_pages, H, hd);
     return launch_attn_decode(static_cast<const bf16_t*>(qkv_dev), 3 * H * hd, static_cast<bf16_t*>(out_dev), rows,
                               stream_dev, ctx_dev, kv, layer, static_cast<hipStream_t>(stream), prefix_page_dev, n_prefix);
+}
+
+extern "C" int t3_op_attn_decode_oproj(const void* qkv_dev, float* slab_dev, int32_t rows, int32_t H, int32_t hd,
+                                       const int32_t* stream_dev, const int32_t* ctx_dev, const void* kv_pool_dev,
+                                       int64_t layer_stride_elems, int32_t layer, const int32_t* block_table_dev,
+                                       int32_t max_pages, const void* wo_dev, int32_t wo_int8, int32_t rows_per_group,
+                                       const int32_t* prefix_page_dev, int32_t n_prefix, void* stream) {
+    T3_REQUIRE(qkv_dev && slab_dev && stream_dev && ctx_dev && kv_pool_dev && block_table_dev && wo_dev, "null argument");
+    const KvView kv = make_kv(const_cast<void*>(kv_pool_dev), layer_stride_elems, block_table_dev, max_pages, H, hd);
+    return launch_attn_decode_oproj(static_cast<const bf16_t*>(qkv_dev), 3 * H * hd, slab_dev, rows, stream_dev, ctx_dev, kv, layer,
+                                    static_cast<const bf16_t*>(wo_dev), wo_int8 != 0, rows_per_group,
+                                    static_cast<hipStream_t>(stream), prefix_page_dev, n_prefix);
+}
+
+extern "C" int t3_op_oproj_split(void) { return ATTN_OPROJ_SPLIT; }
+
+extern "C" int t3_op_head_slab_add_rmsnorm(const float* slab_dev, const float* wo_scale_dev, void* res_dev, const void* w_dev,
+                                           void* xn_dev, int32_t rows, int32_t d, float eps, void* stream) {
+    T3_REQUIRE(slab_dev && res_dev && w_dev && xn_dev, "null argument");
+    return launch_slab_add_rmsnorm(slab_dev, ATTN_OPROJ_SPLIT, static_cast<bf16_t*>(res_dev), static_cast<const bf16_t*>(w_dev),
+                                   static_cast<bf16_t*>(xn_dev), rows, d, eps, static_cast<hipStream_t>(stream), false, nullptr,
+                                   nullptr, nullptr, wo_scale_dev);
 }
 
 static int attn_prefill_op(const void* qkv_dev, void* out_dev, int32_t n_seqs, const int32_t* seq_start_dev,

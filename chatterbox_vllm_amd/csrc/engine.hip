@@ -6,7 +6,8 @@
 // unconditional prompt are zero embeddings).  A decode step runs rows 2i = cond stream and
 // 2i+1 = uncond stream of its B requests through the 30 layers, requests ordered by context length,
 // longest first: the attention grid is dispatched in row order, and starting the long rows first
-// keeps the launch's tail short (measured: 9 % less attention time than arrival order).
+// keeps the launch's tail short (measured: 9 % less attention time than arrival order).  Full steps, whose attention
+// takes four rows per workgroup, pair long requests with short ones instead, so that the workgroups are even.
 //
 // Step = (a) admit waiting requests while a slot, the page reservation and the prompt-row
 // budget allow, (b) prefill the admitted prompts whole and sample their first token,
@@ -153,6 +154,9 @@ struct t3_engine {
     hipEvent_t pjob_done = nullptr;
     bool overlap_prefill = true;
     bool fused_norm = true;                             // few-row decode steps: norm inside the QKV / gate_up projections
+    bool fused_oproj = false;                           // full decode steps: o_proj inside the grouped attention launch (split-K over the heads)
+    int group_rows = ATTN_GROUP_ROWS;                   // rows per workgroup of that form (T3_GROUP_ROWS: 1, 2 or 4)
+    int group_min_rows = 48;                            // decode rows from which the grouped attention + o_proj form runs
     int rows_per_req = 1;                               // rows a request contributes to a step (2 with CFG pairing)
     int kv_per_req = 1;                                 // KV streams a request owns (2 when the uncond stream attends)
     bool uncond_ghost = false;                          // cfg_paired == 2: the uncond row gets no attention and no KV
@@ -376,6 +380,14 @@ int run_layers(t3_engine* e, int rows, const int32_t* d_pos, const int32_t* d_st
     // so the same bits as the separate kernel; gemm.hip).  Every workgroup then reads the residual rows, so the updated
     // rows go to the other of two buffers.
     const bool fuse = !prefill && e->fused_norm && rows <= GEMM_FUSED_NORM_ROWS;
+    // Full decode steps: the attention workgroup of (head, 4 rows) also multiplies its outputs with the head's columns of Wo
+    // (attn.hip): o_proj as a split-K over the heads, no launch of its own, folded by the norm kernel with the additions of
+    // the stand-alone projection's eight slabs (same bits, so a request may pass from one form to the other as the batch
+    // grows and shrinks).  One workgroup per (head, row) would re-read the head's 128 KiB of Wo from L2 once per row, which
+    // costs more than the launch saves (measured at 62 rows: attention 21.2 -> 26.6 us); with few rows there are too few
+    // workgroups to pull Wo at the chip's rate (measured with one row: 1287 against 1333 tokens/s).
+    const bool oproj_in_attn = !prefill && e->fused_oproj && rows >= e->group_min_rows;
+    const int o_split = oproj_in_attn ? ATTN_OPROJ_SPLIT : GEMM_SLAB_SPLIT;
     bf16_t *res = e->b->res, *res_other = e->b->res2;
     for (int li = 0; li < c.n_layers; ++li) {
         const Layer& L = e->layers[li];
@@ -399,20 +411,29 @@ int run_layers(t3_engine* e, int rows, const int32_t* d_pos, const int32_t* d_st
         if (prefill) {
             T3_RUN(e, K_ATTN_PREFILL, li, 2LL * rows * 4 * D, launch_attn_prefill(e->b->qkv, 3 * D, e->b->att, d_seq_start, d_tiles, ntiles, H, hd, st,
                                                                                           d_pfx, kCondRows, &kv, li));
+        } else if (oproj_in_attn) {
+            // decode rows: o_proj runs inside the attention launch, one fp32 partial slab per head
+            T3_RUN(e, K_ATTN_DECODE, li, e->cur_ctx_tokens * 4LL * D + WB * D * D,
+                   launch_attn_decode_oproj(e->b->qkv, 3 * D, e->b->slab, rows, d_stream, d_ctx, kv, li, L.wo, L.so != nullptr,
+                                            e->group_rows, st, d_pfx, kCondRows));
         } else {
             T3_RUN(e, K_ATTN_DECODE, li, e->cur_ctx_tokens * 4LL * D, launch_attn_decode(e->b->qkv, 3 * D, e->b->att, rows, d_stream, d_ctx, kv, li, st,
                                                                                                      d_pfx, kCondRows));
         }
-        GemmArgs o{};
-        o.A = e->b->att; o.lda = D; o.Wt = L.wo; o.wscale = L.so; o.C = e->b->res; o.ldc = D; o.M = rows; o.N = D; o.K = D; o.n_valid = D;
-        o.slab = e->b->slab;
-        T3_RUN(e, K_OPROJ, li, WB * D * D, prefill ? launch_gemm_prompt(EPI_SLAB, o, st) : launch_gemm_slab(o, st));
+        if (!oproj_in_attn) {
+            GemmArgs o{};
+            o.A = e->b->att; o.lda = D; o.Wt = L.wo; o.wscale = L.so; o.C = e->b->res; o.ldc = D; o.M = rows; o.N = D; o.K = D; o.n_valid = D;
+            o.slab = e->b->slab;
+            T3_RUN(e, K_OPROJ, li, WB * D * D, prefill ? launch_gemm_prompt(EPI_SLAB, o, st) : launch_gemm_slab(o, st));
+        }
         if (!fuse)
-            T3_RUN(e, K_NORM, li, 4LL * rows * D, launch_slab_add_rmsnorm(e->b->slab, GEMM_SLAB_SPLIT, res, L.ln2, e->b->xn, rows, D,
-                                                                          c.rms_eps, st, tiled));
+            T3_RUN(e, K_NORM, li, 4LL * rows * D, launch_slab_add_rmsnorm(e->b->slab, o_split, res, L.ln2, e->b->xn, rows, D,
+                                                                          c.rms_eps, st, tiled, nullptr, nullptr, nullptr,
+                                                                          oproj_in_attn ? L.so : nullptr));
         GemmArgs u{};
         if (fuse) {
-            u.fn_w = L.ln2; u.fn_eps = c.rms_eps; u.fn_res_in = res; u.fn_nsplit = GEMM_SLAB_SPLIT;
+            u.fn_w = L.ln2; u.fn_eps = c.rms_eps; u.fn_res_in = res; u.fn_nsplit = o_split;
+            u.fn_pair_scale = oproj_in_attn ? L.so : nullptr;
             u.fn_slab = e->b->slab; u.fn_res_out = res_other;
             std::swap(res, res_other);
         }
@@ -828,13 +849,16 @@ static int engine_create(const t3_config* cfg, hipStream_t caller_stream, bool o
         if (dmalloc(&b.res, R * c.d_model) || dmalloc(&b.xn, R * c.d_model) || dmalloc(&b.qkv, R * 3 * c.d_model) ||
             dmalloc(&b.att, R * c.d_model) || dmalloc(&b.hbuf, R * c.d_ff) || dmalloc(&b.logits, RD * e->head_n) ||
             dmalloc(&b.res2, (size_t)16 * c.d_model)) return 1;
-        T3_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&b.slab), sizeof(float) * GEMM_SLAB_SPLIT * R * c.d_model));
+        T3_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&b.slab), sizeof(float) * ATTN_OPROJ_SPLIT * R * c.d_model));   // 16 head slabs >= 8 split-K slabs
     }
     e->b = &e->bufs;
     if (const char* ug = getenv("T3_USE_GRAPHS")) e->cfg.use_graphs = atoi(ug) != 0;
     if (const char* as = getenv("T3_ASYNC")) e->async_steps = atoi(as) != 0;
     if (const char* ov = getenv("T3_OVERLAP_PREFILL")) e->overlap_prefill = atoi(ov) != 0;
     if (const char* fn = getenv("T3_FUSED_NORM")) e->fused_norm = atoi(fn) != 0;
+    if (const char* fo = getenv("T3_FUSED_OPROJ")) e->fused_oproj = atoi(fo) != 0;
+    if (const char* gm = getenv("T3_GROUP_MIN_ROWS")) e->group_min_rows = std::max(1, atoi(gm));
+    if (const char* gr = getenv("T3_GROUP_ROWS")) { const int v = atoi(gr); if (v == 1 || v == 2 || v == 4) e->group_rows = v; }
     for (int q = 0; q < 2; ++q) {
         T3_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&e->bt_stage[q]), sizeof(int32_t) * e->block_table.n));
         T3_HIP_CHECK(hipEventCreateWithFlags(&e->step_done[q], hipEventDisableTiming));
@@ -1233,6 +1257,18 @@ extern "C" int t3_engine_step(t3_engine* e, int64_t* out_req_ids, int32_t* out_t
         const int ca = a->prompt_len + a->n_launched, cb = b->prompt_len + b->n_launched;
         return ca != cb ? ca > cb : a->slot < b->slot;
     });
+    // The grouped attention form gives one workgroup four consecutive rows: pair the longest request with the shortest, the
+    // second longest with the second shortest, ... so that every group holds about the same number of positions (a row's
+    // tokens do not depend on its place in the batch).
+    if (e->fused_oproj && (int)running.size() * e->rows_per_req >= e->group_min_rows) {
+        std::vector<Request*> paired;
+        paired.reserve(running.size());
+        for (size_t lo = 0, hi = running.size(); lo < hi;) {
+            paired.push_back(running[lo++]);
+            if (lo < hi) paired.push_back(running[--hi]);
+        }
+        running.swap(paired);
+    }
     int row_budget = c.max_prefill_rows;
     while (!e->waiting.empty() && !e->pjob.valid) {
         Request& r = *e->waiting.front();

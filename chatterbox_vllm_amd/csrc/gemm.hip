@@ -168,7 +168,7 @@ __global__ __launch_bounds__(KW * 64) void gemm_stream_kernel(GemmArgs a) {
         float ss = 0.f;
         if (frow < a.M) {
             unpack8(frv, fz);
-            norm_sum8<(FN > 0 ? FN : 0)>(fp, fz);
+            norm_sum8<(FN > 0 ? FN : 0)>(fp, fz, a.fn_pair_scale ? a.fn_pair_scale + ft * 8 : nullptr);
             if constexpr (FN > 0) {
                 if (blockIdx.x == 0 && blockIdx.y == 0)
                     *reinterpret_cast<u32x4*>(a.fn_res_out + (size_t)frow * 1024 + ft * 8) = pack8(fz);
@@ -417,12 +417,16 @@ static int launch_one(const GemmArgs& a, int nblocks, hipStream_t st, int ksplit
 template <int EPI>
 static int launch_fused_norm(const GemmArgs& a, int nblocks, hipStream_t st) {
     T3_REQUIRE(a.M <= GEMM_FUSED_NORM_ROWS && a.K == 1024, "gemm: the norm prologue takes at most 4 rows and K = 1024");
-    T3_REQUIRE(a.fn_res_in && (a.fn_nsplit == 0 || (a.fn_nsplit == GEMM_SLAB_SPLIT && a.fn_slab && a.fn_res_out &&
-                                                    a.fn_res_out != a.fn_res_in)),
-               "gemm: the norm prologue needs the residual rows, and for folded slabs a separate buffer for the new rows");
+    T3_REQUIRE(a.fn_res_in && (a.fn_nsplit == 0 || ((a.fn_nsplit == GEMM_SLAB_SPLIT || a.fn_nsplit == ATTN_OPROJ_SPLIT) &&
+                                                    a.fn_slab && a.fn_res_out && a.fn_res_out != a.fn_res_in)),
+               "gemm: the norm prologue needs the residual rows, and for folded slabs (8 or 16) a separate buffer for the new rows");
     if (a.fn_nsplit == 0) {
         if (a.wscale) return launch_w<2, 1, 8, 4, EPI, true, 0>(a, nblocks, st, 1);
         return launch_w<2, 1, 8, 4, EPI, false, 0>(a, nblocks, st, 1);
+    }
+    if (a.fn_nsplit == ATTN_OPROJ_SPLIT) {
+        if (a.wscale) return launch_w<2, 1, 8, 4, EPI, true, ATTN_OPROJ_SPLIT>(a, nblocks, st, 1);
+        return launch_w<2, 1, 8, 4, EPI, false, ATTN_OPROJ_SPLIT>(a, nblocks, st, 1);
     }
     if (a.wscale) return launch_w<2, 1, 8, 4, EPI, true, GEMM_SLAB_SPLIT>(a, nblocks, st, 1);
     return launch_w<2, 1, 8, 4, EPI, false, GEMM_SLAB_SPLIT>(a, nblocks, st, 1);
@@ -483,7 +487,9 @@ int launch_gemm(int epi, const GemmArgs& a, hipStream_t st) {
 int launch_gemm_slab(const GemmArgs& a, hipStream_t st) {
     T3_REQUIRE(a.slab != nullptr && a.M >= 1 && a.N % 32 == 0 && a.lda % 8 == 0, "gemm_slab: bad arguments");
     if (a.K == 1024 && a.wscale) return launch_mt<2, 2, 2, EPI_SLAB>(a, a.N / 32, st, GEMM_SLAB_SPLIT);   // int8: 2 waves x 1 tile pair
-    if (a.K == 1024) return launch_mt<2, 4, 1, EPI_SLAB>(a, a.N / 32, st, GEMM_SLAB_SPLIT);   // 4 waves x 1 k-tile
+    // K = 1024 (o_proj): split s = heads 2s, 2s+1; wave j chains the two k-tiles of head 2s+j on one accumulator and the two
+    // waves' sums are added: exactly the additions the attention launch + 16-partial fold perform when o_proj runs there
+    if (a.K == 1024) return launch_mt<2, 2, 2, EPI_SLAB>(a, a.N / 32, st, GEMM_SLAB_SPLIT);
     if (a.K == 4096) return launch_mt<2, 8, 2, EPI_SLAB>(a, a.N / 32, st, GEMM_SLAB_SPLIT);   // 8 waves x 2 k-tiles
     t3_set_error("gemm_slab: K must be 1024 or 4096");
     return 1;

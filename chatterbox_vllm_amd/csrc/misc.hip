@@ -65,7 +65,8 @@ __global__ __launch_bounds__(SLAB_NORM_THREADS) void slab_add_rmsnorm_kernel(con
                                                                const bf16_t* __restrict__ w, bf16_t* __restrict__ xn,
                                                                float eps, int xn_tiled, const bf16_t* __restrict__ emb,
                                                                const int32_t* __restrict__ emb_slot,
-                                                               const int32_t* __restrict__ last_token) {
+                                                               const int32_t* __restrict__ last_token,
+                                                               const float* __restrict__ pair_scale) {
     constexpr int d = 1024;
     __shared__ float part[2];
     const size_t row = blockIdx.x;
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(SLAB_NORM_THREADS) void slab_add_rmsnorm_kernel(con
         unpack8(*reinterpret_cast<const u32x4*>(res + row * d + c), z);
     }
     if constexpr (NSPLIT > 0) {
-        norm_fold8<NSPLIT>(slab + row * d + c, slab_stride, z);
+        norm_fold8<NSPLIT>(slab + row * d + c, slab_stride, z, pair_scale ? pair_scale + c : nullptr);
         *reinterpret_cast<u32x4*>(res + row * d + c) = pack8(z);
     }
     const float ss = wave_sum(norm_ssq8(z));
@@ -98,17 +99,22 @@ __global__ __launch_bounds__(SLAB_NORM_THREADS) void slab_add_rmsnorm_kernel(con
 
 int launch_slab_add_rmsnorm(const float* slab, int nsplit, bf16_t* res, const bf16_t* w, bf16_t* xn, int rows, int d,
                             float eps, hipStream_t st, bool xn_tiled, const bf16_t* emb, const int32_t* emb_slot,
-                            const int32_t* last_token) {
+                            const int32_t* last_token, const float* pair_scale) {
+    T3_REQUIRE(pair_scale == nullptr || nsplit == ATTN_OPROJ_SPLIT, "slab_add_rmsnorm: a pair scale belongs to the 16 head partials");
     T3_REQUIRE(emb == nullptr || (nsplit == 0 && emb_slot && last_token), "slab_add_rmsnorm: the embedding gather belongs to the first norm");
     T3_REQUIRE(rows >= 1 && d == 1024, "slab_add_rmsnorm: d must be 1024");
     static_assert(SLAB_NORM_THREADS == 128, "8 columns per thread, two waves per row");
-    T3_REQUIRE(nsplit == 0 || (slab != nullptr && nsplit == GEMM_SLAB_SPLIT), "slab_add_rmsnorm: nsplit must be 0 or the split count");
-    if (nsplit == 0)
+    T3_REQUIRE(nsplit == 0 || (slab != nullptr && (nsplit == GEMM_SLAB_SPLIT || nsplit == ATTN_OPROJ_SPLIT)),
+               "slab_add_rmsnorm: nsplit must be 0, the split-K count (8) or the head count (16)");
+    if (nsplit == ATTN_OPROJ_SPLIT)
+        T3_LAUNCH(slab_add_rmsnorm_kernel<ATTN_OPROJ_SPLIT>, dim3(rows), dim3(SLAB_NORM_THREADS), 0, st, slab, (size_t)rows * d, res, w, xn,
+                  eps, (int)xn_tiled, emb, emb_slot, last_token, pair_scale);
+    else if (nsplit == 0)
         T3_LAUNCH(slab_add_rmsnorm_kernel<0>, dim3(rows), dim3(SLAB_NORM_THREADS), 0, st, slab, (size_t)rows * d, res, w, xn, eps,
-                  (int)xn_tiled, emb, emb_slot, last_token);
+                  (int)xn_tiled, emb, emb_slot, last_token, pair_scale);
     else
         T3_LAUNCH(slab_add_rmsnorm_kernel<GEMM_SLAB_SPLIT>, dim3(rows), dim3(SLAB_NORM_THREADS), 0, st, slab, (size_t)rows * d, res, w, xn,
-                  eps, (int)xn_tiled, emb, emb_slot, last_token);
+                  eps, (int)xn_tiled, emb, emb_slot, last_token, pair_scale);
     T3_HIP_CHECK(hipGetLastError());
     return 0;
 }

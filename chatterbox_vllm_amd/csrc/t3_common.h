@@ -45,24 +45,42 @@ __device__ __forceinline__ void norm_load8(const float* __restrict__ sp, size_t 
 #pragma unroll
         for (int v = 0; v < 2; ++v) p[s][v] = *reinterpret_cast<const f32x4*>(sp + s * slab_stride + 4 * v);
 }
+// NSPLIT == ATTN_OPROJ_SPLIT (16): the partials are o_proj's per-head sums written by the attention launch; heads 2s and
+// 2s+1 together are what split-K slab s of the stand-alone projection holds, so they are added first (and, for int8 weights,
+// scaled by the column's weight scale, which that projection applies to its slab) and the eight pair sums then fold like
+// eight slabs: the same additions in the same order, hence the same bits as the stand-alone projection's eight slabs.
 template <int NSPLIT>
-__device__ __forceinline__ void norm_sum8(const f32x4 (&p)[NSPLIT > 0 ? NSPLIT : 1][2], float z[8]) {
+__device__ __forceinline__ void norm_sum8(const f32x4 (&p)[NSPLIT > 0 ? NSPLIT : 1][2], float z[8], const float* __restrict__ pair_scale = nullptr) {
     if constexpr (NSPLIT > 0) {
 #pragma unroll
         for (int v = 0; v < 2; ++v) {
-            f32x4 a = p[0][v];
+            f32x4 a;
+            if constexpr (NSPLIT == 16) {
+                f32x4 sc = {1.f, 1.f, 1.f, 1.f};
+                if (pair_scale) sc = *reinterpret_cast<const f32x4*>(pair_scale + 4 * v);
+                a = p[0][v] + p[1][v];
+                if (pair_scale) a *= sc;
 #pragma unroll
-            for (int s = 1; s < NSPLIT; ++s) a += p[s][v];
+                for (int s = 1; s < 8; ++s) {
+                    f32x4 b = p[2 * s][v] + p[2 * s + 1][v];
+                    if (pair_scale) b *= sc;
+                    a += b;
+                }
+            } else {
+                a = p[0][v];
+#pragma unroll
+                for (int s = 1; s < NSPLIT; ++s) a += p[s][v];
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) z[4 * v + i] = rbf(rbf(a[i]) + z[4 * v + i]);
         }
     }
 }
 template <int NSPLIT>
-__device__ __forceinline__ void norm_fold8(const float* __restrict__ sp, size_t slab_stride, float z[8]) {
+__device__ __forceinline__ void norm_fold8(const float* __restrict__ sp, size_t slab_stride, float z[8], const float* __restrict__ pair_scale = nullptr) {
     f32x4 p[NSPLIT > 0 ? NSPLIT : 1][2];
     norm_load8<NSPLIT>(sp, slab_stride, p);
-    norm_sum8<NSPLIT>(p, z);
+    norm_sum8<NSPLIT>(p, z, pair_scale);
 }
 __device__ __forceinline__ float norm_ssq8(const float z[8]) {
     float ss = 0.f;
@@ -134,6 +152,8 @@ struct KvView {
 // ---- launchers (all asynchronous on `st`) -------------------------------------------
 enum GemmEpilogue { EPI_STORE = 0, EPI_RESID = 1, EPI_SILU = 2, EPI_QKV_ROPE = 3, EPI_SLAB = 4, EPI_STORE_GATHER = 5 };
 #define GEMM_SLAB_SPLIT 8          // K is cut into 8 block-level ranges in the split-K (slab) form
+#define ATTN_GROUP_ROWS 4          // rows one workgroup of the grouped decode attention takes (attn.hip)
+#define ATTN_OPROJ_SPLIT 16        // partial slabs of o_proj when it runs inside the decode attention launch: one per head
 #define GEMM_FUSED_NORM_ROWS 4     // launches of at most this many rows can take the residual-add + RMSNorm into the projection
 
 struct GemmArgs {
@@ -159,6 +179,7 @@ struct GemmArgs {
     // and multiplies with rmsnorm(res') * fn_w, bit for bit what launch_slab_add_rmsnorm would have handed it; workgroup 0
     // stores res' to fn_res_out (a buffer other than fn_res_in: every workgroup reads fn_res_in)
     const float* fn_slab; int fn_nsplit; const bf16_t* fn_res_in; bf16_t* fn_res_out; const bf16_t* fn_w; float fn_eps;
+    const float* fn_pair_scale;        // fn_nsplit == ATTN_OPROJ_SPLIT with int8 o_proj weights: its [1024] column scales, else nullptr
 #ifdef T3_GEMM_TIMELINE
     long long* ts;                     // tools/gemm_timeline.hip: [block][wave][8] wall-clock stamps
 #endif
@@ -182,7 +203,8 @@ int launch_gemm_prompt(int epi, const GemmArgs& a, hipStream_t st);
 // xn = rmsnorm(res) * w.  One pass, the row stays in registers.
 int launch_slab_add_rmsnorm(const float* slab, int nsplit, bf16_t* res, const bf16_t* w, bf16_t* xn, int rows, int d,
                             float eps, hipStream_t st, bool xn_tiled = false, const bf16_t* emb = nullptr,
-                            const int32_t* emb_slot = nullptr, const int32_t* last_token = nullptr);
+                            const int32_t* emb_slot = nullptr, const int32_t* last_token = nullptr,
+                            const float* pair_scale = nullptr);
 int launch_repack(const bf16_t* w, bf16_t* wt, int N, int K, hipStream_t st);
 // W[N,K] bf16 -> int8 pair tiles (offset binary) + scale[N] = absmax(row) / 127 (1 for an all-zero row)
 int launch_quantize(const bf16_t* w, uint8_t* wq, float* scale, int N, int K, hipStream_t st);
@@ -192,6 +214,10 @@ int launch_add_rmsnorm(const bf16_t* x, bf16_t* res, const bf16_t* w, bf16_t* xn
 int launch_attn_decode(const bf16_t* qkv, int ldq, bf16_t* out, int rows, const int32_t* row_stream,
                        const int32_t* row_ctx, const KvView& kv, int layer, hipStream_t st,
                        const int32_t* row_pfx = nullptr, int npfx = 0);
+// the same with o_proj in the launch: slab[head][row][0..1024) fp32, to be folded by launch_slab_add_rmsnorm(nsplit = ATTN_OPROJ_SPLIT)
+int launch_attn_decode_oproj(const bf16_t* qkv, int ldq, float* slab, int rows, const int32_t* row_stream,
+                             const int32_t* row_ctx, const KvView& kv, int layer, const bf16_t* wo, bool int8,
+                             int rows_per_group, hipStream_t st, const int32_t* row_pfx = nullptr, int npfx = 0);
 // tiles_dev: (sequence index, first query row) per 64-row query tile.  seq_pfx_dev (optional): per sequence, the
 // pool page holding keys [0, npfx) when the sequence's rows start at position npfx, or -1 (rows start at 0)
 int launch_attn_prefill(const bf16_t* qkv, int ldq, bf16_t* out, const int32_t* seq_start_dev,

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define T3_ABI_VERSION 3
+#define T3_ABI_VERSION 4
 
 typedef struct t3_engine t3_engine;
 
@@ -191,7 +191,7 @@ int t3_op_gemm(const void* a_dev, const void* wt_dev, void* out_dev, int32_t M, 
 int t3_op_gemm_slab(const void* a_dev, const void* wt_dev, float* slab_dev, int32_t M, int32_t N, int32_t K, void* stream);
 int t3_op_slab_split(void);
 /* res = bf16(bf16(slab[0] + ... + slab[nsplit-1]) + res) (skipped when nsplit == 0), then
- * xn = rmsnorm(res) * w; d must be 1024.  The decode-path partner of t3_op_gemm_slab. */
+ * xn = rmsnorm(res) * w; d must be 1024; nsplit 0 or t3_op_slab_split().  The decode-path partner of t3_op_gemm_slab. */
 int t3_op_slab_add_rmsnorm(const float* slab_dev, int32_t nsplit, void* res_dev, const void* w_dev, void* xn_dev,
                            int32_t rows, int32_t d, float eps, void* stream);
 /* Same with xn written in activation tile order (t3_gemm_desc), what the decode step's projections read. */
@@ -249,8 +249,9 @@ typedef struct t3_gemm_desc {
     const void* fn_res_in_dev;    /* [M, 1024] bf16                                                              */
     void* fn_res_out_dev;         /* [M, 1024] bf16 (fn_nsplit > 0)                                              */
     const void* fn_norm_w_dev;    /* [1024] bf16; NULL = no norm prologue                                        */
-    int32_t fn_nsplit;            /* 0 or t3_op_slab_split()                                                     */
+    int32_t fn_nsplit;            /* 0, t3_op_slab_split(), or t3_op_oproj_split() (head partials, folded pairwise)  */
     float fn_eps;
+    const float* fn_pair_scale_dev; /* fn_nsplit 16 with int8 o_proj weights: their [1024] column scales; else NULL  */
 } t3_gemm_desc;
 int t3_op_gemm_ex(const t3_gemm_desc* desc, void* stream);
 /* Single-query attention over the paged KV cache: row r attends to positions
@@ -259,6 +260,25 @@ int t3_op_attn_decode(const void* qkv_dev, void* out_dev, int32_t rows, int32_t 
                       const int32_t* stream_dev, const int32_t* ctx_dev, const void* kv_pool_dev,
                       int64_t layer_stride_elems, int32_t layer, const int32_t* block_table_dev,
                       int32_t max_pages, void* stream);
+/* Attention of (row, head) and, in the same launch, that head's share of o_proj (self_attn.o_proj of the vLLM
+ * LlamaAttention reached from t3.py:768-773): what full decode steps run.  slab_dev [t3_op_oproj_split() = 16 heads]
+ * [rows][H*hd] fp32 receives bf16(attention output of head h) x Wq[:, h*hd .. (h+1)*hd)^T with Wq = Wo (bf16 tiles of
+ * t3_op_repack_weight), or, with wo_int8 set, the UNSCALED int8 values of the pair tiles of t3_op_quantize_weight (the
+ * fold applies the scales).  rows_per_group: 1 = one workgroup per (head, row); 4 = one workgroup per (head, 4 consecutive
+ * rows), which reads the head's weights once per four rows; both give the same bits.  The fold
+ * (t3_op_head_slab_add_rmsnorm, or the norm prologue of t3_op_gemm_ex with fn_nsplit 16) adds heads 2s and 2s+1, scales, and
+ * sums the eight pairs in order: the additions t3_op_gemm_slab + t3_op_slab_add_rmsnorm perform, so the bits are the same.
+ * prefix_page_dev may be NULL (no shared prefix). */
+int t3_op_attn_decode_oproj(const void* qkv_dev, float* slab_dev, int32_t rows, int32_t H, int32_t hd,
+                            const int32_t* stream_dev, const int32_t* ctx_dev, const void* kv_pool_dev,
+                            int64_t layer_stride_elems, int32_t layer, const int32_t* block_table_dev,
+                            int32_t max_pages, const void* wo_dev, int32_t wo_int8, int32_t rows_per_group,
+                            const int32_t* prefix_page_dev, int32_t n_prefix, void* stream);
+int t3_op_oproj_split(void);
+/* res = bf16(bf16(sum over s of scale * (slab[2s] + slab[2s+1])) + res), xn = rmsnorm(res) * w, for the 16 head partials
+ * of t3_op_attn_decode_oproj; wo_scale_dev [d] fp32 or NULL (bf16 weights). */
+int t3_op_head_slab_add_rmsnorm(const float* slab_dev, const float* wo_scale_dev, void* res_dev, const void* w_dev,
+                                void* xn_dev, int32_t rows, int32_t d, float eps, void* stream);
 /* Causal attention inside packed prompt rows: sequence i owns rows [seq_start[i], seq_start[i+1]). */
 int t3_op_attn_prefill(const void* qkv_dev, void* out_dev, int32_t n_seqs, const int32_t* seq_start_dev,
                        const int32_t* seq_start_host, int32_t H, int32_t hd, void* stream);

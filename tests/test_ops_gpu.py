@@ -233,6 +233,86 @@ def test_attn_decode_matches_softmax_attention(capi):
     assert torch.equal(one[0], out[2])
 
 
+@pytest.mark.parametrize("int8", [False, True])
+def test_attn_decode_with_output_projection_in_the_launch(capi, int8):
+    """t3_op_attn_decode_oproj: attention of (row, head) and that head's share of o_proj in one launch (what full decode
+    steps run, four rows per workgroup).  Its 16 head partials, added pairwise (and scaled, for int8 weights), ARE the eight
+    split-K slabs t3_op_gemm_slab computes from the stored attention output, bit for bit; so the fold
+    (t3_op_head_slab_add_rmsnorm) gives the bits of t3_op_slab_add_rmsnorm over those eight slabs.  A row alone in a
+    launch has identical bits; a row without a stream (no attention) projects to zero."""
+    H, hd = 16, 64
+    ctxs = [1, 64, 65, 200, 513, 1000, 37]
+    n = len(ctxs)
+    max_pages = 16
+    pool, bt, layer_stride = _kv_setup(n, max_pages, 2, seed=5)
+    pool.copy_(_rand(tuple(pool.shape), 22, 3.0))
+    for s, c in enumerate(ctxs):
+        _fill_cache(pool, layer_stride, 1, bt, s, _rand((c, H, hd), 130 + s).to(DEV), _rand((c, H, hd), 160 + s).to(DEV))
+    qkv = torch.zeros(n, 3 * H * hd, dtype=torch.bfloat16, device=DEV)
+    qkv[:, : H * hd] = _rand((n, H * hd), 23).to(DEV)
+    stream_d = torch.arange(n, dtype=torch.int32, device=DEV)
+    stream_d[6] = -1                                             # a row that gets no attention
+    ctx_d = torch.tensor(ctxs, dtype=torch.int32, device=DEV)
+    ctx_d[6] = 0
+    bt_d = bt.to(DEV)
+    wo = _rand((1024, 1024), 24, 0.02).to(DEV)
+    att = torch.zeros(n, H * hd, dtype=torch.bfloat16, device=DEV)
+    call(capi, "t3_op_attn_decode", p(qkv), p(att), n, H, hd, p(stream_d), p(ctx_d), p(pool), layer_stride, 1, p(bt_d),
+         max_pages, None)
+    from chatterbox_vllm_amd._capi import T3GemmDesc
+    desc = T3GemmDesc()
+    if int8:
+        wq = torch.empty(1024 * 1024, dtype=torch.uint8, device=DEV)
+        sc = torch.empty(1024, dtype=torch.float32, device=DEV)
+        call(capi, "t3_op_quantize_weight", p(wo), p(wq), p(sc), 1024, 1024, None)
+        wt, wsc = wq, sc
+    else:
+        wt, wsc = repack(capi, wo), None
+    nsp, n8 = capi.t3_op_oproj_split(), capi.t3_op_slab_split()
+    assert nsp == 16 and n8 == 8
+    heads = torch.full((nsp, n, 1024), 7.0, dtype=torch.float32, device=DEV)
+    call(capi, "t3_op_attn_decode_oproj", p(qkv), p(heads), n, H, hd, p(stream_d), p(ctx_d), p(pool), layer_stride, 1,
+         p(bt_d), max_pages, p(wt), int(int8), 4, None, 0, None)
+    # one workgroup per (head, row) instead of per (head, 4 rows): the same bits
+    heads1 = torch.full((nsp, n, 1024), 5.0, dtype=torch.float32, device=DEV)
+    call(capi, "t3_op_attn_decode_oproj", p(qkv), p(heads1), n, H, hd, p(stream_d), p(ctx_d), p(pool), layer_stride, 1,
+         p(bt_d), max_pages, p(wt), int(int8), 1, None, 0, None)
+    torch.cuda.synchronize()
+    assert torch.equal(heads1, heads)
+    # the stand-alone projection of the stored attention rows: eight split-K slabs
+    slab8 = torch.full((n8, n, 1024), -7.0, dtype=torch.float32, device=DEV)
+    desc.a_dev, desc.w_dev, desc.w_scale_dev, desc.slab_dev = att.data_ptr(), wt.data_ptr(), (wsc.data_ptr() if int8 else None), slab8.data_ptr()
+    desc.M, desc.N, desc.K, desc.epilogue = n, 1024, 1024, 4
+    call(capi, "t3_op_gemm_ex", C.byref(desc), None)
+    torch.cuda.synchronize()
+    assert torch.equal(att[6], torch.zeros_like(att[6])) and not heads[:, 6].any()
+    pairs = heads[0::2] + heads[1::2]
+    if int8:
+        pairs = pairs * sc[None, None, :]
+    assert torch.equal(pairs, slab8), "head partials, added pairwise, are not the stand-alone projection's slabs"
+    # and against plain arithmetic: o_proj of the stored attention rows
+    w_eff = (W.quantize_int8(wo.cpu())[0].float() * W.quantize_int8(wo.cpu())[1][:, None]).to(DEV) if int8 else wo.float()
+    proj = att.float() @ w_eff.T
+    assert (slab8.sum(0) - proj).abs().max().item() <= 1e-4 * float(proj.abs().max()) + 1e-6
+    # the two folds give the same residual rows and normalised rows
+    nw = (1 + 0.1 * _rand((1024,), 26).float()).to(torch.bfloat16).to(DEV)
+    res_a = _rand((n, 1024), 25).to(DEV)
+    res_b = res_a.clone()
+    xn_a = torch.zeros(n, 1024, dtype=torch.bfloat16, device=DEV)
+    xn_b = torch.zeros_like(xn_a)
+    call(capi, "t3_op_head_slab_add_rmsnorm", p(heads), p(wsc), p(res_a), p(nw), p(xn_a), n, 1024, C.c_float(1e-5), None)
+    call(capi, "t3_op_slab_add_rmsnorm", p(slab8), n8, p(res_b), p(nw), p(xn_b), n, 1024, C.c_float(1e-5), None)
+    torch.cuda.synchronize()
+    assert torch.equal(res_a, res_b) and torch.equal(xn_a, xn_b)
+    # one row alone in a launch: identical bits
+    one = torch.zeros(nsp, 1, 1024, dtype=torch.float32, device=DEV)
+    q1, s1, c1 = qkv[4:5].contiguous(), stream_d[4:5].contiguous(), ctx_d[4:5].contiguous()
+    call(capi, "t3_op_attn_decode_oproj", p(q1), p(one), 1, H, hd, p(s1), p(c1), p(pool), layer_stride, 1,
+         p(bt_d), max_pages, p(wt), int(int8), 4, None, 0, None)
+    torch.cuda.synchronize()
+    assert torch.equal(one[:, 0], heads[:, 4])
+
+
 def test_attn_prefill_is_causal_per_sequence(capi):
     H, hd = 16, 64
     lens = [1, 43, 64, 65, 200]

@@ -62,8 +62,9 @@ int main(int argc, char** argv) {
     hipGraph_t g; hipGraphExec_t ge;
     CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
     for (int i = 0; i < L; ++i)
-        hipLaunchKernelGGL(attn_decode_kernel, dim3(H, rows), dim3(ATT_NW * 64), 0, st, qkv, 3 * H * hd, out, H * hd,
-                           d_rs, d_rc, kv, i % layers, (const int32_t*)nullptr, 0, ts + per * i);
+        hipLaunchKernelGGL((attn_decode_kernel<1, false, false>), dim3(H, rows), dim3(ATT_NW * 64), 0, st, qkv, 3 * H * hd, out, H * hd,
+                           rows, d_rs, d_rc, kv, i % layers, (const int32_t*)nullptr, 0, (const bf16_t*)nullptr,
+                           (float*)nullptr, ts + per * i);
     CK(hipStreamEndCapture(st, &g));
     CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
     for (int r = 0; r < 3; ++r) CK(hipGraphLaunch(ge, st));

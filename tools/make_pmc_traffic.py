@@ -3,21 +3,34 @@
    python3 tools/make_pmc_traffic.py gpurun_out/r01 > profiles/pmc_traffic.json
 Keys are the engine's kernel classes; bytes_per_launch = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes), the
 mean over every launch of that kernel in one pass of the benchmark job."""
-import json, sys
+import hashlib, json, os, sys
 tag = sys.argv[1]
+
+
+def kernel_source_sha():
+    """sha256 (16 hex digits) over the kernel sources: bench.py quotes the traffic only for the build it was measured on."""
+    h = hashlib.sha256()
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "chatterbox_vllm_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".h")):
+            with open(os.path.join(csrc, name), "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 f = json.load(open(tag + "_pmc_fetch.json"))["FETCH_SIZE"]
 w = json.load(open(tag + "_pmc_write.json"))["WRITE_SIZE"]
 # gemm_stream_kernel<NB, MT, KW, KT, EPI, W8, FN>: the full-batch (33-64 row) bf16 variants of the decode step
 classes = {
-    "attn_decode": ["attn_decode_kernel"],
+    "attn_decode": ["void attn_decode_kernel<1, false, false>"],
     "gemm_gateup_silu": ["void gemm_stream_kernel<2, 4, 8, 4, 2, false, -1>"],
     "gemm_qkv_rope": ["void gemm_stream_kernel<2, 2, 8, 4, 3, false, -1>"],
     "gemm_down_resid": ["void gemm_stream_kernel<2, 4, 8, 2, 4, false, -1>"],
-    "gemm_o_resid": ["void gemm_stream_kernel<2, 4, 4, 1, 4, false, -1>"],
+    "gemm_o_resid": ["void gemm_stream_kernel<2, 4, 2, 2, 4, false, -1>"],
     "add_rmsnorm": ["void slab_add_rmsnorm_kernel<8>"],
     "gemm_head": ["void gemm_stream_kernel<3, 4, 8, 4, 0, false, -1>"],
 }
-out = {}
+out = {"kernel_source_sha16": kernel_source_sha()}
 for cls, names in classes.items():
     for n in names:
         if n in f:

@@ -33,8 +33,8 @@ class T3Config(C.Structure):
 class T3Sampling(C.Structure):
     _fields_ = [
         ("temperature", C.c_float), ("top_p", C.c_float), ("min_p", C.c_float), ("repetition_penalty", C.c_float),
-        ("max_tokens", C.c_int32), ("stop_token", C.c_int32), ("has_seed", C.c_int32), ("reserved0", C.c_int32),
-        ("seed", C.c_uint64),
+        ("max_tokens", C.c_int32), ("stop_token", C.c_int32), ("has_seed", C.c_int32), ("n_extra_stop", C.c_int32),
+        ("seed", C.c_uint64), ("extra_stop_tokens", C.c_int32 * 4),
     ]
 
 
@@ -116,6 +116,9 @@ SIGNATURES = {
                            C.c_int32, _P], C.c_int),
     "t3_op_attn_decode_oproj": ([_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, C.c_int64, C.c_int32, _P,
                                  C.c_int32, _P, C.c_int32, C.c_int32, _P, C.c_int32, _P], C.c_int),
+    "t3_op_attn_states_floats": ([C.c_int32], C.c_int),
+    "t3_op_attn_decode_split_oproj": ([_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, C.c_int64, C.c_int32, _P,
+                                       C.c_int32, _P, _P, _P, C.c_int32, _P], C.c_int),
     "t3_op_oproj_split": ([], C.c_int),
     "t3_op_head_slab_add_rmsnorm": ([_P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_float, _P], C.c_int),
     "t3_op_attn_prefill": ([_P, _P, C.c_int32, _P, _I32P, C.c_int32, C.c_int32, _P], C.c_int),

@@ -129,9 +129,9 @@ __device__ __forceinline__ void att_merge_groups(float& m, float& l, float (&o)[
         const float m2 = __shfl_xor(m, off), l2 = __shfl_xor(l, off);
         const float mn = fmaxf(m, m2);
         const float a1 = __expf(m - mn), a2 = __expf(m2 - mn);
-        l = l * a1 + l2 * a2;
+        l = fmaf(l, a1, l2 * a2);                     // explicit, so that every instantiation rounds alike
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = o[j] * a1 + __shfl_xor(o[j], off) * a2;
+        for (int j = 0; j < 8; ++j) o[j] = fmaf(o[j], a1, __shfl_xor(o[j], off) * a2);
         m = mn;
     }
 }
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(ATT_NW * 64, (RPW > 2 || (OPROJ && RPW == 1)) ? 2 :
 #define ATT_STAMP(i) do { } while (0)
 #endif
     ATT_STAMP(0);
-    __shared__ float part[RPW][ATT_NW][8][12];
+    __shared__ float part[RPW][ATT_NW][8][ATT_STATE_FLOATS];
     __shared__ __attribute__((aligned(16))) bf16_t o_sh[RPW][64];
     const int h = blockIdx.x, r0 = blockIdx.y * RPW;
     const int nr = rows - r0 < RPW ? rows - r0 : RPW;              // rows of this group
@@ -243,22 +243,7 @@ __global__ __launch_bounds__(ATT_NW * 64, (RPW > 2 || (OPROJ && RPW == 1)) ? 2 :
     __syncthreads();
     if (threadIdx.x < 8 * RPW) {
         const int i = threadIdx.x >> 3;                     // row of the group; c = threadIdx.x & 7
-        float M = part[i][0][c][0], L = part[i][0][c][1], O[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) O[j] = part[i][0][c][2 + j];
-        for (int w2 = 1; w2 < ATT_NW; ++w2) {
-            const float m2 = part[i][w2][c][0], l2 = part[i][w2][c][1];
-            const float mn = fmaxf(M, m2);
-            const float a1 = __expf(M - mn), a2 = __expf(m2 - mn);
-            L = L * a1 + l2 * a2;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) O[j] = O[j] * a1 + part[i][w2][c][2 + j] * a2;
-            M = mn;
-        }
-        const float inv = L > 0.f ? 1.0f / L : 0.f;
-        u32x4 ov;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) ov[k] = pack_bf2(O[2 * k] * inv, O[2 * k + 1] * inv);
+        const u32x4 ov = att_merge_waves(&part[i][0][c][0], 8 * ATT_STATE_FLOATS);
         if constexpr (OPROJ) *reinterpret_cast<u32x4*>(&o_sh[i][c * 8]) = ov;
         else if (i < nr) *reinterpret_cast<u32x4*>(out + (size_t)(r0 + i) * ldo + h * hd + c * 8) = ov;
     }
@@ -292,7 +277,55 @@ __global__ __launch_bounds__(ATT_NW * 64, (RPW > 2 || (OPROJ && RPW == 1)) ? 2 :
     ATT_STAMP(4);
 }
 
+// Few-row form: grid (head, row, wave): the work of ONE wave of attn_decode_kernel<1, ...> per single-wave workgroup, its
+// merged lane-group state stored to states[((row * H + head) * ATT_NW + wave) * 8 + c][ATT_STATE_FLOATS].
+__global__ __launch_bounds__(64) void attn_decode_split_kernel(
+        const bf16_t* __restrict__ qkv, int ldq, float* __restrict__ states,
+        const int32_t* __restrict__ row_stream, const int32_t* __restrict__ row_ctx, KvView kv, int layer,
+        const int32_t* __restrict__ row_pfx, int npfx) {
+    const int h = blockIdx.x, r = blockIdx.y, w = blockIdx.z;
+    const int lane = threadIdx.x;
+    const int c = lane & 7, tg = lane >> 3;
+    const int st = row_stream[r];
+    const int ctx = row_ctx[r];
+    const int pfx = row_pfx ? row_pfx[r] : -1;
+    const bf16_t* lbase = kv.pool + (size_t)layer * kv.layer_stride;
+    float q[8], m = -1e30f, l = 0.f, o[8];
+    {
+        const u32x4 qv = *reinterpret_cast<const u32x4*>(qkv + (size_t)r * ldq + h * 64 + c * 8);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { q[2 * k] = bf_lo(qv[k]); q[2 * k + 1] = bf_hi(qv[k]); }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = 0.f;
+    const int nt = st >= 0 ? (ctx + 63) >> 6 : 0;
+    AttTile t;
+    for (int tile = w; tile < nt; tile += ATT_NW) {
+        att_load_tile(t, lbase, kv, st, tile, h, lane, pfx, npfx);
+        att_fold_tile(t, q, tile, ctx, tg, m, l, o);
+    }
+    att_merge_groups(m, l, o);
+    if (tg == 0) {
+        float* sp = states + ((((size_t)r * kv.H + h) * ATT_NW + w) * 8 + c) * ATT_STATE_FLOATS;
+        *reinterpret_cast<f32x4*>(sp) = f32x4{m, l, o[0], o[1]};
+        *reinterpret_cast<f32x4*>(sp + 4) = f32x4{o[2], o[3], o[4], o[5]};
+        *reinterpret_cast<f32x4*>(sp + 8) = f32x4{o[6], o[7], 0.f, 0.f};
+    }
+}
+
 #ifndef T3_ATTN_TIMELINE
+int launch_attn_decode_split(const bf16_t* qkv, int ldq, float* states, int rows, const int32_t* row_stream,
+                             const int32_t* row_ctx, const KvView& kv, int layer, hipStream_t st,
+                             const int32_t* row_pfx, int npfx) {
+    T3_REQUIRE(kv.hd == 64, "attn_decode_split: head_dim must be 64");
+    T3_REQUIRE(rows >= 1 && ldq % 8 == 0 && states, "attn_decode_split: bad arguments");
+    T3_REQUIRE(row_pfx == nullptr || (npfx >= 1 && npfx <= T3_PAGE), "attn_decode: the shared prefix must fit one page");
+    T3_LAUNCH(attn_decode_split_kernel, dim3(kv.H, rows, ATT_NW), dim3(64), 0, st, qkv, ldq, states, row_stream, row_ctx, kv,
+              layer, row_pfx, npfx);
+    T3_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int launch_attn_decode(const bf16_t* qkv, int ldq, bf16_t* out, int rows, const int32_t* row_stream,
                        const int32_t* row_ctx, const KvView& kv, int layer, hipStream_t st,
                        const int32_t* row_pfx, int npfx) {

@@ -197,6 +197,26 @@ extern "C" int t3_op_attn_decode_oproj(const void* qkv_dev, float* slab_dev, int
 
 extern "C" int t3_op_oproj_split(void) { return ATTN_OPROJ_SPLIT; }
 
+extern "C" int t3_op_attn_states_floats(int32_t H) { return H * 8 * 8 * ATT_STATE_FLOATS; }
+
+extern "C" int t3_op_attn_decode_split_oproj(const void* qkv_dev, float* states_dev, float* slab_dev, int32_t rows, int32_t H,
+                                             int32_t hd, const int32_t* stream_dev, const int32_t* ctx_dev,
+                                             const void* kv_pool_dev, int64_t layer_stride_elems, int32_t layer,
+                                             const int32_t* block_table_dev, int32_t max_pages, const void* wo_dev,
+                                             const float* wo_scale_dev, const int32_t* prefix_page_dev, int32_t n_prefix,
+                                             void* stream) {
+    T3_REQUIRE(qkv_dev && states_dev && slab_dev && stream_dev && ctx_dev && kv_pool_dev && block_table_dev && wo_dev, "null argument");
+    T3_REQUIRE(rows >= 1 && rows <= GEMM_FUSED_NORM_ROWS && H == 16 && hd == 64, "the split form takes 1..4 rows of 16 heads x 64");
+    const KvView kv = make_kv(const_cast<void*>(kv_pool_dev), layer_stride_elems, block_table_dev, max_pages, H, hd);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (int rc = launch_attn_decode_split(static_cast<const bf16_t*>(qkv_dev), 3 * H * hd, states_dev, rows, stream_dev, ctx_dev, kv,
+                                          layer, st, prefix_page_dev, n_prefix)) return rc;
+    GemmArgs o{};
+    o.a_states = states_dev; o.lda = H * hd; o.Wt = static_cast<const bf16_t*>(wo_dev); o.wscale = wo_scale_dev;
+    o.M = rows; o.N = H * hd; o.K = H * hd; o.n_valid = o.N; o.ldc = o.N; o.slab = slab_dev;
+    return launch_gemm_slab(o, st);
+}
+
 extern "C" int t3_op_head_slab_add_rmsnorm(const float* slab_dev, const float* wo_scale_dev, void* res_dev, const void* w_dev,
                                            void* xn_dev, int32_t rows, int32_t d, float eps, void* stream) {
     T3_REQUIRE(slab_dev && res_dev && w_dev && xn_dev, "null argument");

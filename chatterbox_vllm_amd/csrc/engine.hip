@@ -155,6 +155,9 @@ struct t3_engine {
     bool overlap_prefill = true;
     bool fused_norm = true;                             // few-row decode steps: norm inside the QKV / gate_up projections
     bool fused_oproj = false;                           // full decode steps: o_proj inside the grouped attention launch (split-K over the heads)
+    bool split_attn = false;                            // few-row decode steps: attention split over single-wave workgroups
+                                                        // (T3_SPLIT_ATTN=1; measured: attention 7.6 -> 6.0 us, o_proj 3.5 -> 4.3 us,
+                                                        // single stream 1330 -> 1295 tokens/s, so off)
     int group_rows = ATTN_GROUP_ROWS;                   // rows per workgroup of that form (T3_GROUP_ROWS: 1, 2 or 4)
     int group_min_rows = 48;                            // decode rows from which the grouped attention + o_proj form runs
     int rows_per_req = 1;                               // rows a request contributes to a step (2 with CFG pairing)
@@ -190,6 +193,7 @@ struct t3_engine {
     struct Bufs {
         bf16_t *res = nullptr, *xn = nullptr, *qkv = nullptr, *att = nullptr, *hbuf = nullptr, *logits = nullptr;
         bf16_t* res2 = nullptr;                         // second residual buffer of the few-row decode form (GEMM_FUSED_NORM_ROWS rows)
+        float* att_states = nullptr;                    // few-row decode form: per-wave softmax states of the split attention
         float* slab = nullptr;                          // [GEMM_SLAB_SPLIT][rows][d] fp32 split-K partials (decode)
     } bufs, pbufs;                                      // decode rows / prompt rows
     Bufs* b = &bufs;
@@ -388,6 +392,7 @@ int run_layers(t3_engine* e, int rows, const int32_t* d_pos, const int32_t* d_st
     // workgroups to pull Wo at the chip's rate (measured with one row: 1287 against 1333 tokens/s).
     const bool oproj_in_attn = !prefill && e->fused_oproj && rows >= e->group_min_rows;
     const int o_split = oproj_in_attn ? ATTN_OPROJ_SPLIT : GEMM_SLAB_SPLIT;
+    const bool split_attn = !prefill && !oproj_in_attn && e->split_attn && rows <= GEMM_FUSED_NORM_ROWS;
     bf16_t *res = e->b->res, *res_other = e->b->res2;
     for (int li = 0; li < c.n_layers; ++li) {
         const Layer& L = e->layers[li];
@@ -411,6 +416,12 @@ int run_layers(t3_engine* e, int rows, const int32_t* d_pos, const int32_t* d_st
         if (prefill) {
             T3_RUN(e, K_ATTN_PREFILL, li, 2LL * rows * 4 * D, launch_attn_prefill(e->b->qkv, 3 * D, e->b->att, d_seq_start, d_tiles, ntiles, H, hd, st,
                                                                                           d_pfx, kCondRows, &kv, li));
+        } else if (split_attn) {
+            // a few rows: one single-wave workgroup per (head, row, wave), so that a row's K/V are pulled by eight CUs;
+            // o_proj merges the wave states itself (same arithmetic, same bits as the one-workgroup form).  The merge in
+            // the prologue of all 256 o_proj workgroups costs what the shorter attention launch gains.
+            T3_RUN(e, K_ATTN_DECODE, li, e->cur_ctx_tokens * 4LL * D,
+                   launch_attn_decode_split(e->b->qkv, 3 * D, e->b->att_states, rows, d_stream, d_ctx, kv, li, st, d_pfx, kCondRows));
         } else if (oproj_in_attn) {
             // decode rows: o_proj runs inside the attention launch, one fp32 partial slab per head
             T3_RUN(e, K_ATTN_DECODE, li, e->cur_ctx_tokens * 4LL * D + WB * D * D,
@@ -424,6 +435,7 @@ int run_layers(t3_engine* e, int rows, const int32_t* d_pos, const int32_t* d_st
             GemmArgs o{};
             o.A = e->b->att; o.lda = D; o.Wt = L.wo; o.wscale = L.so; o.C = e->b->res; o.ldc = D; o.M = rows; o.N = D; o.K = D; o.n_valid = D;
             o.slab = e->b->slab;
+            if (split_attn) o.a_states = e->b->att_states;
             T3_RUN(e, K_OPROJ, li, WB * D * D, prefill ? launch_gemm_prompt(EPI_SLAB, o, st) : launch_gemm_slab(o, st));
         }
         if (!fuse)
@@ -849,6 +861,8 @@ static int engine_create(const t3_config* cfg, hipStream_t caller_stream, bool o
         if (dmalloc(&b.res, R * c.d_model) || dmalloc(&b.xn, R * c.d_model) || dmalloc(&b.qkv, R * 3 * c.d_model) ||
             dmalloc(&b.att, R * c.d_model) || dmalloc(&b.hbuf, R * c.d_ff) || dmalloc(&b.logits, RD * e->head_n) ||
             dmalloc(&b.res2, (size_t)16 * c.d_model)) return 1;
+        T3_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&b.att_states),
+                               sizeof(float) * GEMM_FUSED_NORM_ROWS * c.n_heads * 8 * 8 * ATT_STATE_FLOATS));
         T3_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&b.slab), sizeof(float) * ATTN_OPROJ_SPLIT * R * c.d_model));   // 16 head slabs >= 8 split-K slabs
     }
     e->b = &e->bufs;
@@ -857,6 +871,7 @@ static int engine_create(const t3_config* cfg, hipStream_t caller_stream, bool o
     if (const char* ov = getenv("T3_OVERLAP_PREFILL")) e->overlap_prefill = atoi(ov) != 0;
     if (const char* fn = getenv("T3_FUSED_NORM")) e->fused_norm = atoi(fn) != 0;
     if (const char* fo = getenv("T3_FUSED_OPROJ")) e->fused_oproj = atoi(fo) != 0;
+    if (const char* sa = getenv("T3_SPLIT_ATTN")) e->split_attn = atoi(sa) != 0;
     if (const char* gm = getenv("T3_GROUP_MIN_ROWS")) e->group_min_rows = std::max(1, atoi(gm));
     if (const char* gr = getenv("T3_GROUP_ROWS")) { const int v = atoi(gr); if (v == 1 || v == 2 || v == 4) e->group_rows = v; }
     for (int q = 0; q < 2; ++q) {
@@ -1010,7 +1025,7 @@ extern "C" int t3_engine_destroy(t3_engine* e) {
     for (auto* bp : {&e->bufs, &e->pbufs}) {
         auto& b = *bp;
         (void)hipFree(b.res); (void)hipFree(b.xn); (void)hipFree(b.qkv); (void)hipFree(b.att); (void)hipFree(b.hbuf);
-        (void)hipFree(b.logits); (void)hipFree(b.slab); (void)hipFree(b.res2);
+        (void)hipFree(b.logits); (void)hipFree(b.slab); (void)hipFree(b.res2); (void)hipFree(b.att_states);
     }
     (void)hipFree(e->cond_buf); (void)hipFree(e->seen); (void)hipFree(e->last_token); (void)hipFree(e->dbg_logits);
     for (int q = 0; q < 2; ++q) {
@@ -1050,7 +1065,8 @@ extern "C" int t3_engine_add_request(t3_engine* e, int64_t req_id, const int32_t
     T3_REQUIRE(P <= c.max_prefill_rows, "prompt longer than max_prefill_rows");
     for (int i = 0; i < n_text; ++i)
         T3_REQUIRE(text_ids[i] >= 0 && text_ids[i] < c.text_vocab, "text id outside the text vocabulary");
-    T3_REQUIRE(sp->max_tokens >= 1 && sp->repetition_penalty > 0.f, "bad sampling parameters");
+    T3_REQUIRE(sp->max_tokens >= 1 && sp->repetition_penalty > 0.f && sp->n_extra_stop >= 0 && sp->n_extra_stop <= 4,
+               "bad sampling parameters");
     for (auto& w : e->waiting) T3_REQUIRE(w->id != req_id, "duplicate request id");
     for (auto& s : e->slots) T3_REQUIRE(!s || s->id != req_id, "duplicate request id");
     std::unique_ptr<Request> r(new Request());
@@ -1168,7 +1184,8 @@ void account_token(t3_engine* e, Request* r, int32_t tok, int64_t* out_req_ids, 
     int fin = 0;
     if (tok < 0) { fin = 3; r->poisoned = true; }             // the sampler found no finite logit
     else if (tok == r->sp.stop_token) fin = 1;
-    else if (r->n_out >= r->limit) fin = 2;
+    else for (int j = 0; j < r->sp.n_extra_stop; ++j) if (tok == r->sp.extra_stop_tokens[j]) fin = 1;
+    if (!fin && r->n_out >= r->limit) fin = 2;
     out_req_ids[k] = r->id; out_tokens[k] = tok; out_finished[k] = fin; ++k;
     if (!fin) return;
     if (r->n_launched > r->n_out) r->zombie = true;           // the next step already carries it

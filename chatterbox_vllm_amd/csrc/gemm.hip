@@ -45,7 +45,9 @@ __device__ __forceinline__ bf16x8 dequant8(unsigned lo, unsigned hi) {
 // FN >= 0: residual-add + RMSNorm in the prologue (launches of at most GEMM_FUSED_NORM_ROWS rows, one row tile): wave pair
 // (2r, 2r+1) does for row r what slab_add_rmsnorm_kernel<FN> does with its 128 threads, the normalised row tile goes to LDS
 // in activation tile order and the MFMA operands come from there.  FN is the number of split-K slabs to fold in.
-template <int NB, int MT, int KW, int KT, int EPI, bool W8, int FN = -1>
+// AM: the activation rows are attention outputs that this kernel merges itself from the per-wave softmax states of the
+// few-row split attention (EPI_SLAB, K = 1024, one row tile, KT = 2: the wave's two k-tiles are one head).
+template <int NB, int MT, int KW, int KT, int EPI, bool W8, int FN = -1, bool AM = false>
 __global__ __launch_bounds__(KW * 64) void gemm_stream_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) float red_raw[];
     f32x4* red = reinterpret_cast<f32x4*>(red_raw);
@@ -93,6 +95,7 @@ __global__ __launch_bounds__(KW * 64) void gemm_stream_kernel(GemmArgs a) {
     const int a_step = a.a_tiled ? 512 : 32;         // elements from one k-tile's fragment to the next
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
+        if constexpr (AM) { arow[mt] = nullptr; continue; }
         if (a.a_tiled) {                              // wave-uniform: activation tile order, 1 KiB per fragment
             int tile = (m0 >> 4) + mt;
             const int last = (a.M - 1) >> 4;
@@ -129,6 +132,21 @@ __global__ __launch_bounds__(KW * 64) void gemm_stream_kernel(GemmArgs a) {
             frv = *reinterpret_cast<const u32x4*>(a.fn_res_in + (size_t)frow * 1024 + ft * 8);
             fwv = *reinterpret_cast<const u32x4*>(a.fn_w + ft * 8);
             norm_load8<(FN > 0 ? FN : 0)>(a.fn_slab + (size_t)frow * 1024 + ft * 8, (size_t)a.M * 1024, fp);
+        }
+    }
+    // AM: lane (row = lane & 15, g = lane >> 4) needs dims 8g..8g+7 of k-tile kt of head kt0 / 2: column group c = 4 kt + g of
+    // that head's attention output, merged from the eight wave states exactly as the attention kernel merges them
+    bf16x8 am[AM ? KT : 1];
+    if constexpr (AM) {
+        static_assert(!AM || (MT == 1 && KT == 2 && EPI == EPI_SLAB), "the state merge feeds the o_proj slab form");
+        const int row = lane & 15, head = kt0 >> 1;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (row < a.M)
+                v = att_merge_waves(a.a_states + ((((size_t)row * 16 + head) * 8) * 8 + 4 * kt + (lane >> 4)) * ATT_STATE_FLOATS,
+                                    8 * ATT_STATE_FLOATS);
+            am[kt] = __builtin_bit_cast(bf16x8, v);
         }
     }
     // weight fragments: the HBM stream
@@ -189,6 +207,7 @@ __global__ __launch_bounds__(KW * 64) void gemm_stream_kernel(GemmArgs a) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             if constexpr (FN >= 0) af[mt] = *reinterpret_cast<const bf16x8*>(fn_tile + ((kt0 + kt) * 64 + lane) * 8);
+            else if constexpr (AM) af[mt] = am[kt];
             else af[mt] = *reinterpret_cast<const bf16x8*>(arow[mt] + kt * a_step);
         }
 #pragma unroll
@@ -383,7 +402,7 @@ int launch_quantize(const bf16_t* w, uint8_t* wq, float* scale, int N, int K, hi
     return 0;
 }
 
-template <int NB, int MT, int KW, int KT, int EPI, bool W8, int FN = -1>
+template <int NB, int MT, int KW, int KT, int EPI, bool W8, int FN = -1, bool AM = false>
 static int launch_w(const GemmArgs& a, int nblocks, hipStream_t st, int ksplit) {
     constexpr size_t lds = (size_t)KW * NB * MT * 64 * sizeof(f32x4);
     // the attribute belongs to the kernel's copy on ONE device: set it once per device this variant is launched on
@@ -392,12 +411,12 @@ static int launch_w(const GemmArgs& a, int nblocks, hipStream_t st, int ksplit) 
     T3_HIP_CHECK(hipGetDevice(&dev));
     T3_REQUIRE(dev >= 0 && dev < T3_MAX_DEVICES, "gemm: device ordinal out of range");
     if (!attr_set[dev]) {
-        T3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_stream_kernel<NB, MT, KW, KT, EPI, W8, FN>),
+        T3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_stream_kernel<NB, MT, KW, KT, EPI, W8, FN, AM>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set[dev] = true;
     }
     const int groups = (a.M + MT * 16 - 1) / (MT * 16);
-    T3_LAUNCH((gemm_stream_kernel<NB, MT, KW, KT, EPI, W8, FN>), dim3(nblocks, groups, ksplit), dim3(KW * 64), lds, st, a);
+    T3_LAUNCH((gemm_stream_kernel<NB, MT, KW, KT, EPI, W8, FN, AM>), dim3(nblocks, groups, ksplit), dim3(KW * 64), lds, st, a);
     T3_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -486,6 +505,11 @@ int launch_gemm(int epi, const GemmArgs& a, hipStream_t st) {
 // are summed in split order by the residual-add + RMSNorm kernel that follows.
 int launch_gemm_slab(const GemmArgs& a, hipStream_t st) {
     T3_REQUIRE(a.slab != nullptr && a.M >= 1 && a.N % 32 == 0 && a.lda % 8 == 0, "gemm_slab: bad arguments");
+    if (a.a_states) {                                 // o_proj behind the few-row split attention: rows merged in the kernel
+        T3_REQUIRE(a.K == 1024 && a.N == 1024 && a.M <= GEMM_FUSED_NORM_ROWS, "gemm_slab: the state merge is built for o_proj of at most 4 rows");
+        if (a.wscale) return launch_w<2, 1, 2, 2, EPI_SLAB, true, -1, true>(a, a.N / 32, st, GEMM_SLAB_SPLIT);
+        return launch_w<2, 1, 2, 2, EPI_SLAB, false, -1, true>(a, a.N / 32, st, GEMM_SLAB_SPLIT);
+    }
     if (a.K == 1024 && a.wscale) return launch_mt<2, 2, 2, EPI_SLAB>(a, a.N / 32, st, GEMM_SLAB_SPLIT);   // int8: 2 waves x 1 tile pair
     // K = 1024 (o_proj): split s = heads 2s, 2s+1; wave j chains the two k-tiles of head 2s+j on one accumulator and the two
     // waves' sums are added: exactly the additions the attention launch + 16-partial fold perform when o_proj runs there

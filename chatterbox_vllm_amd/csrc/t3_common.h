@@ -107,6 +107,31 @@ __device__ __forceinline__ u32x4 pack8(const float z[8]) {
     return o;
 }
 
+// ---- decode attention: merge of the eight per-wave softmax states of one (row, head, 8-dim column group) ------------
+// sp[w * wave_stride + 0..9] = m, l, o[0..7] of wave w.  Waves are folded in order 0..7; returns the 8 normalised outputs
+// as bf16.  Shared by the attention kernel (states in LDS) and by the o_proj kernel that follows the few-row split form
+// (states in memory): the same operations in the same order, so the same bits.
+__device__ __forceinline__ u32x4 att_merge_waves(const float* sp, int wave_stride) {
+    float M = sp[0], L = sp[1], O[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) O[j] = sp[2 + j];
+    for (int w2 = 1; w2 < 8; ++w2) {
+        const float* p = sp + (size_t)w2 * wave_stride;
+        const float m2 = p[0], l2 = p[1];
+        const float mn = fmaxf(M, m2);
+        const float a1 = __expf(M - mn), a2 = __expf(m2 - mn);
+        L = fmaf(L, a1, l2 * a2);                     // explicit: the compiler's own contraction may differ between kernels
+#pragma unroll
+        for (int j = 0; j < 8; ++j) O[j] = fmaf(O[j], a1, p[2 + j] * a2);
+        M = mn;
+    }
+    const float inv = L > 0.f ? 1.0f / L : 0.f;
+    u32x4 ov;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ov[k] = pack_bf2(O[2 * k] * inv, O[2 * k + 1] * inv);
+    return ov;
+}
+
 // ---- error plumbing (host) -------------------------------------------------------
 void t3_set_error(const std::string& msg);
 #define T3_HIP_CHECK(expr)                                                                   \
@@ -180,6 +205,10 @@ struct GemmArgs {
     // stores res' to fn_res_out (a buffer other than fn_res_in: every workgroup reads fn_res_in)
     const float* fn_slab; int fn_nsplit; const bf16_t* fn_res_in; bf16_t* fn_res_out; const bf16_t* fn_w; float fn_eps;
     const float* fn_pair_scale;        // fn_nsplit == ATTN_OPROJ_SPLIT with int8 o_proj weights: its [1024] column scales, else nullptr
+    // EPI_SLAB, K = 1024, M <= GEMM_FUSED_NORM_ROWS (o_proj of a few-row decode step): when a_states is set, A is unused and
+    // the rows are the attention outputs merged here from the per-wave softmax states that launch_attn_decode_split left
+    // (attn.hip), with the arithmetic of the attention kernel's own merge: the same bits as its stored output
+    const float* a_states;
 #ifdef T3_GEMM_TIMELINE
     long long* ts;                     // tools/gemm_timeline.hip: [block][wave][8] wall-clock stamps
 #endif
@@ -214,6 +243,13 @@ int launch_add_rmsnorm(const bf16_t* x, bf16_t* res, const bf16_t* w, bf16_t* xn
 int launch_attn_decode(const bf16_t* qkv, int ldq, bf16_t* out, int rows, const int32_t* row_stream,
                        const int32_t* row_ctx, const KvView& kv, int layer, hipStream_t st,
                        const int32_t* row_pfx = nullptr, int npfx = 0);
+// Few-row steps: one single-wave workgroup per (head, row, wave of the kernel above); each leaves its softmax state
+// (m, l, o[8] per 8-dim column group: ATT_STATE_FLOATS floats) in states[row][head][wave][column group] instead of merging in LDS,
+// so that one row's K/V stream is pulled by up to eight CUs instead of one.  The projection that follows merges them.
+#define ATT_STATE_FLOATS 12
+int launch_attn_decode_split(const bf16_t* qkv, int ldq, float* states, int rows, const int32_t* row_stream,
+                             const int32_t* row_ctx, const KvView& kv, int layer, hipStream_t st,
+                             const int32_t* row_pfx = nullptr, int npfx = 0);
 // the same with o_proj in the launch: slab[head][row][0..1024) fp32, to be folded by launch_slab_add_rmsnorm(nsplit = ATTN_OPROJ_SPLIT)
 int launch_attn_decode_oproj(const bf16_t* qkv, int ldq, float* slab, int rows, const int32_t* row_stream,
                              const int32_t* row_ctx, const KvView& kv, int layer, const bf16_t* wo, bool int8,

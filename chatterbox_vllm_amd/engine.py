@@ -80,12 +80,17 @@ class T3Engine:
                  max_model_len: int = 1000, max_num_seqs: int = 32, cfg_scale: Optional[float] = None,
                  cfg_paired: Optional[bool] = None, device: int = 0, enforce_eager: bool = False,
                  kv_pages: int = 0, max_prefill_rows: int = 2048, quantization: Optional[str] = None,
-                 scheduling_policy: str = "fcfs", uncond_attends: bool = True, prefix_sharing: bool = True,
+                 scheduling_policy: str = "fcfs", uncond_attends: Optional[bool] = None, prefix_sharing: bool = True,
                  max_voices: int = 0, stream: Optional[int] = None, **_ignored_vllm_kwargs):
         if cfg_scale is None:                      # models/t3/t3.py:343
             cfg_scale = float(os.environ.get("CHATTERBOX_CFG_SCALE", "0.5"))
         if cfg_paired is None:
-            cfg_paired = True                      # the reference always runs both halves
+            cfg_paired = True                      # the reference's model doubles every row into a cond and an uncond half (t3.py:762-772)
+        if uncond_attends is None:
+            # What the uncond half attends to is decided inside the serving stack the reference runs on, which is not part
+            # of it: the documented intent is a second stream with its own K/V (the default here); the other reading, an
+            # uncond row without attention output or K/V, is selected with CHATTERBOX_UNCOND_ATTENDS=0 (or the argument).
+            uncond_attends = os.environ.get("CHATTERBOX_UNCOND_ATTENDS", "1") not in ("0", "false", "False")
         self.model_config = model_config
         self.tokenizer = tokenizer
         self.max_model_len = int(max_model_len)
@@ -158,11 +163,12 @@ class T3Engine:
         ids = (C.c_int32 * len(text_ids))(*[int(t) for t in text_ids])
         cond = cond_emb.detach().to(device="cpu", dtype=torch.float32).contiguous()
         stop = list(sp.stop_token_ids or [])
-        if len(stop) > 1:
-            raise ValueError("the T3 engine supports a single stop token id")
+        if len(stop) > 5:
+            raise ValueError("the T3 engine supports at most 5 stop token ids per request")
         s = _capi.T3Sampling(temperature=sp.temperature, top_p=sp.top_p, min_p=sp.min_p,
                              repetition_penalty=sp.repetition_penalty, max_tokens=int(sp.max_tokens),
-                             stop_token=int(stop[0]) if stop else -1, has_seed=int(sp.seed is not None), reserved0=0,
+                             stop_token=int(stop[0]) if stop else -1, has_seed=int(sp.seed is not None),
+                             n_extra_stop=max(0, len(stop) - 1), extra_stop_tokens=(C.c_int32 * 4)(*([int(t) for t in stop[1:]] + [0] * (5 - max(1, len(stop))))),
                              seed=int(sp.seed or 0) & (2 ** 64 - 1))
         _capi.check(self._lib, self._lib.t3_engine_add_request(
             self._h, rid, ids, len(text_ids), C.cast(_capi.ptr(cond), C.POINTER(C.c_float)), C.byref(s)))

@@ -61,10 +61,11 @@ typedef struct t3_config {
 typedef struct t3_sampling {
     float temperature, top_p, min_p, repetition_penalty;
     int32_t max_tokens;
-    int32_t stop_token;        /* in the engine's +1000 id space (7562)               */
+    int32_t stop_token;        /* in the engine's +1000 id space (7562); -1 = none    */
     int32_t has_seed;
-    int32_t reserved0;
+    int32_t n_extra_stop;      /* further stop ids in extra_stop_tokens (0..3): vllm.SamplingParams.stop_token_ids is a list */
     uint64_t seed;
+    int32_t extra_stop_tokens[4];
 } t3_sampling;
 
 /* Counters of the last t3_engine_step (for benchmarks / tracing). */
@@ -275,6 +276,19 @@ int t3_op_attn_decode_oproj(const void* qkv_dev, float* slab_dev, int32_t rows, 
                             int32_t max_pages, const void* wo_dev, int32_t wo_int8, int32_t rows_per_group,
                             const int32_t* prefix_page_dev, int32_t n_prefix, void* stream);
 int t3_op_oproj_split(void);
+
+/* Decode attention for steps of 1..4 rows (a single stream, the tail of a queue) followed by o_proj.  One single-wave
+ * workgroup per (head, row, eighth of the context) leaves its online-softmax state in states_dev
+ * (rows x t3_op_attn_states_floats(H) fp32); the o_proj kernel merges the eight states of a (row, head) itself, with the
+ * arithmetic of t3_op_attn_decode's merge, and writes the eight split-K slabs of t3_op_gemm_slab bit for bit
+ * (slab_dev [8][rows][H*hd] fp32).  wo_scale_dev NULL for bf16 weights.  Same reference lines as t3_op_attn_decode:
+ * vLLM's paged decode attention behind src/chatterbox_vllm/models/t3/t3.py:282-300. */
+int t3_op_attn_states_floats(int32_t H);
+int t3_op_attn_decode_split_oproj(const void* qkv_dev, float* states_dev, float* slab_dev, int32_t rows, int32_t H,
+                                  int32_t hd, const int32_t* stream_dev, const int32_t* ctx_dev, const void* kv_pool_dev,
+                                  int64_t layer_stride_elems, int32_t layer, const int32_t* block_table_dev,
+                                  int32_t max_pages, const void* wo_dev, const float* wo_scale_dev,
+                                  const int32_t* prefix_page_dev, int32_t n_prefix, void* stream);
 /* res = bf16(bf16(sum over s of scale * (slab[2s] + slab[2s+1])) + res), xn = rmsnorm(res) * w, for the 16 head partials
  * of t3_op_attn_decode_oproj; wo_scale_dev [d] fp32 or NULL (bf16 weights). */
 int t3_op_head_slab_add_rmsnorm(const float* slab_dev, const float* wo_scale_dev, void* res_dev, const void* w_dev,

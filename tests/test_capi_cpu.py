@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header_sizes():
     # t3_config: 16 int32 + 2 float + int64 + 2 int32 ; t3_sampling: 4 float + 4 int32 + uint64
     assert C.sizeof(_capi.T3Config) == 16 * 4 + 2 * 4 + 8 + 2 * 4
-    assert C.sizeof(_capi.T3Sampling) == 4 * 4 + 4 * 4 + 8
+    assert C.sizeof(_capi.T3Sampling) == 4 * 4 + 4 * 4 + 8 + 4 * 4
     assert C.sizeof(_capi.T3StepStats) == 4 * 4 + 8 + 4 * 4 + 2 * 4
     # t3_gemm_desc: 5 pointers + 10 int32 + 4 pointers + int64 + pointer + 2 int32 + 4 pointers + int32 + float
     assert C.sizeof(_capi.T3GemmDesc) == 5 * 8 + 10 * 4 + 4 * 8 + 8 + 8 + 2 * 4 + 4 * 8 + 4 + 4 + 8

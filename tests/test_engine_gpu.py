@@ -260,6 +260,11 @@ def test_stop_and_length_rules(small):
     sp2 = SamplingParams(temperature=0.0, repetition_penalty=2.0, max_tokens=50, stop_token_ids=[out.token_ids[2]])
     out2 = eng.generate(items, sp2)[0].outputs[0]
     assert out2.token_ids == out.token_ids[:3] and out2.finish_reason == "stop"
+    # stop_token_ids is a list (vllm.SamplingParams): the first of several ids that comes up ends the request
+    sp3 = SamplingParams(temperature=0.0, repetition_penalty=2.0, max_tokens=50,
+                         stop_token_ids=[out.token_ids[4], 999999, out.token_ids[1], out.token_ids[3]])
+    out3 = eng.generate(items, sp3)[0].outputs[0]
+    assert out3.token_ids == out.token_ids[:2] and out3.finish_reason == "stop"
     with pytest.raises(ValueError):
         eng.generate(_items([_text(P + 10, 8)], [0]), sp)
     assert not eng.has_unfinished()
@@ -268,6 +273,41 @@ def test_stop_and_length_rules(small):
     with pytest.raises(Exception):
         eng.generate([{"prompt_token_ids": [255, 9999, 0], "multi_modal_data": {"conditionals": [W.synthetic_cond_emb(0)]}}], sp)
     eng.shutdown()
+
+
+@pytest.mark.parametrize("form", ["oproj_in_attention", "split_attention"])
+def test_alternative_decode_forms_give_the_same_bits(small, monkeypatch, form):
+    """The two decode forms that are built, measured slower and therefore off by default (o_proj inside the attention
+    launch; the few-row attention split over single-wave workgroups with the merge inside o_proj) must still give the
+    default form's ids and the default form's logits bit for bit, so that turning one on changes timing only."""
+    cfg, sd = small
+    n = 1 if form == "split_attention" else 3
+    texts = [_text(k, 700 + k) for k in (9, 40, 17)][:n]
+
+    def run(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = T3Engine(cfg, sd, max_model_len=256, max_num_seqs=4, cfg_scale=3.0)
+        eng.set_keep_logits(True)
+        sp = SamplingParams(temperature=0.0, repetition_penalty=2.0, max_tokens=12)
+        rids = [eng.add_request(t, W.synthetic_cond_emb(i), sp) for i, t in enumerate(texts)]
+        ids, logits = {r: [] for r in rids}, {r: [] for r in rids}
+        while eng.has_unfinished():
+            for rid, tok, fin in eng.step():
+                ids[rid].append(tok)
+                if fin is None:
+                    logits[rid].append(eng.last_logits(rid).clone())
+        eng.shutdown()
+        for k in env:
+            monkeypatch.delenv(k)
+        return [ids[r] for r in rids], [torch.stack(logits[r]) for r in rids]
+
+    base_ids, base_logits = run({})
+    env = {"T3_SPLIT_ATTN": "1"} if form == "split_attention" else {"T3_FUSED_OPROJ": "1", "T3_GROUP_MIN_ROWS": "2"}
+    alt_ids, alt_logits = run(env)
+    assert alt_ids == base_ids
+    for a, b in zip(alt_logits, base_logits):
+        assert torch.equal(a, b)
 
 
 def test_pipelined_steps_match_synchronous_steps(small, monkeypatch):

@@ -313,6 +313,55 @@ def test_attn_decode_with_output_projection_in_the_launch(capi, int8):
     assert torch.equal(one[:, 0], heads[:, 4])
 
 
+@pytest.mark.parametrize("int8", [False, True])
+@pytest.mark.parametrize("rows", [1, 2, 4])
+def test_few_row_split_attention_feeds_o_proj_the_same_bits(capi, rows, int8):
+    """t3_op_attn_decode_split_oproj (decode steps of 1..4 rows: eight single-wave workgroups per (row, head), the states
+    merged inside the o_proj kernel) writes the eight slabs that t3_op_attn_decode + t3_op_gemm_slab write, bit for bit:
+    a request may pass between the two forms as the batch grows and shrinks."""
+    H, hd = 16, 64
+    ctxs = [1000, 65, 1, 513][:rows]
+    max_pages = 16
+    pool, bt, layer_stride = _kv_setup(rows, max_pages, 2, seed=6)
+    pool.copy_(_rand(tuple(pool.shape), 42, 3.0))
+    for s, c in enumerate(ctxs):
+        _fill_cache(pool, layer_stride, 1, bt, s, _rand((c, H, hd), 230 + s).to(DEV), _rand((c, H, hd), 260 + s).to(DEV))
+    qkv = torch.zeros(rows, 3 * H * hd, dtype=torch.bfloat16, device=DEV)
+    qkv[:, : H * hd] = _rand((rows, H * hd), 43).to(DEV)
+    stream_d = torch.arange(rows, dtype=torch.int32, device=DEV)
+    ctx_d = torch.tensor(ctxs, dtype=torch.int32, device=DEV)
+    if rows == 4:
+        stream_d[2] = -1                                         # a row that gets no attention
+        ctx_d[2] = 0
+    bt_d = bt.to(DEV)
+    wo = _rand((1024, 1024), 44, 0.02).to(DEV)
+    if int8:
+        wt = torch.empty(1024 * 1024, dtype=torch.uint8, device=DEV)
+        sc = torch.empty(1024, dtype=torch.float32, device=DEV)
+        call(capi, "t3_op_quantize_weight", p(wo), p(wt), p(sc), 1024, 1024, None)
+    else:
+        wt, sc = repack(capi, wo), None
+    att = torch.zeros(rows, H * hd, dtype=torch.bfloat16, device=DEV)
+    call(capi, "t3_op_attn_decode", p(qkv), p(att), rows, H, hd, p(stream_d), p(ctx_d), p(pool), layer_stride, 1, p(bt_d),
+         max_pages, None)
+    n8 = capi.t3_op_slab_split()
+    want = torch.full((n8, rows, 1024), -7.0, dtype=torch.float32, device=DEV)
+    from chatterbox_vllm_amd._capi import T3GemmDesc
+    desc = T3GemmDesc()
+    desc.a_dev, desc.w_dev, desc.w_scale_dev, desc.slab_dev = att.data_ptr(), wt.data_ptr(), (sc.data_ptr() if int8 else None), want.data_ptr()
+    desc.M, desc.N, desc.K, desc.epilogue = rows, 1024, 1024, 4
+    call(capi, "t3_op_gemm_ex", C.byref(desc), None)
+    states = torch.full((rows * capi.t3_op_attn_states_floats(H),), float("nan"), dtype=torch.float32, device=DEV)
+    got = torch.full((n8, rows, 1024), 7.0, dtype=torch.float32, device=DEV)
+    call(capi, "t3_op_attn_decode_split_oproj", p(qkv), p(states), p(got), rows, H, hd, p(stream_d), p(ctx_d), p(pool),
+         layer_stride, 1, p(bt_d), max_pages, p(wt), p(sc), None, 0, None)
+    torch.cuda.synchronize()
+    assert att.float().abs().max().item() > 0.1
+    assert torch.equal(got, want)
+    if rows == 4:
+        assert not got[:, 2].any()
+
+
 def test_attn_prefill_is_causal_per_sequence(capi):
     H, hd = 16, 64
     lens = [1, 43, 64, 65, 200]

@@ -1,7 +1,7 @@
 """Prompt text normalisation and the language table.
 
 Behaviour follows src/chatterbox_vllm/text_utils.py:2-41 (``punc_norm``) and :44-68
-(``SUPPORTED_LANGUAGES``) of the reference; tests/test_text.py pins it against strings
+(``SUPPORTED_LANGUAGES``) of the reference; tests/test_host_cpu.py pins it against strings
 captured from the reference function (tests/golden/ref_text_fixture.json).
 """
 from __future__ import annotations

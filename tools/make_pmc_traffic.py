@@ -23,12 +23,12 @@ w = json.load(open(tag + "_pmc_write.json"))["WRITE_SIZE"]
 # gemm_stream_kernel<NB, MT, KW, KT, EPI, W8, FN>: the full-batch (33-64 row) bf16 variants of the decode step
 classes = {
     "attn_decode": ["void attn_decode_kernel<1, false, false>"],
-    "gemm_gateup_silu": ["void gemm_stream_kernel<2, 4, 8, 4, 2, false, -1>"],
-    "gemm_qkv_rope": ["void gemm_stream_kernel<2, 2, 8, 4, 3, false, -1>"],
-    "gemm_down_resid": ["void gemm_stream_kernel<2, 4, 8, 2, 4, false, -1>"],
-    "gemm_o_resid": ["void gemm_stream_kernel<2, 4, 2, 2, 4, false, -1>"],
+    "gemm_gateup_silu": ["void gemm_stream_kernel<2, 4, 8, 4, 2, false, -1, false>"],
+    "gemm_qkv_rope": ["void gemm_stream_kernel<2, 2, 8, 4, 3, false, -1, false>"],
+    "gemm_down_resid": ["void gemm_stream_kernel<2, 4, 8, 2, 4, false, -1, false>"],
+    "gemm_o_resid": ["void gemm_stream_kernel<2, 4, 2, 2, 4, false, -1, false>"],
     "add_rmsnorm": ["void slab_add_rmsnorm_kernel<8>"],
-    "gemm_head": ["void gemm_stream_kernel<3, 4, 8, 4, 0, false, -1>"],
+    "gemm_head": ["void gemm_stream_kernel<3, 4, 8, 4, 0, false, -1, false>"],
 }
 out = {"kernel_source_sha16": kernel_source_sha()}
 for cls, names in classes.items():

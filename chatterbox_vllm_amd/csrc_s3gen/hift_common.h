@@ -1,0 +1,56 @@
+// Shared declarations of libs3hift.so (HiFT vocoder on gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <string>
+#include "../../include/s3hift_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum { ACT_NONE = 0, ACT_SNAKE = 1, ACT_LRELU = 2, ACT_ELU = 3 };
+enum { ACC_NONE = 0, ACC_SET = 1, ACC_ADD = 2, ACC_ADD_DIV3 = 3 };
+
+#define CONV_CK 16          // input channels per LDS tile
+#define CONV_MAX_HALO 52    // (K - 1) * dilation of the widest layer is 50
+
+// One convolution launch.  Tensors are [batch][channel][time] fp32 with a row stride (x_ld, y_ld) and a batch stride.
+struct ConvArgs {
+    const float* x; size_t x_bs; int x_ld; int Tin;
+    const float* wt;                    // tile order: ((cb * K + tap) * (Cin / 8) + g) * 256 + lane * 4 + j  =
+                                        //   W[cb * 32 + lane % 32][g * 8 + 2 j + lane / 32][tap], zero above Cout
+    const float* bias;                  // [Cout]
+    const float* alpha;                 // [Cin], Snake only
+    float* y; size_t y_bs; int y_ld; int Tout;     // y may be null (accumulate only); res / res2 / acc share its layout
+    const float* res; const float* res2;
+    float* acc; int acc_mode;
+    int Cin, Cout, CoutPad, K, dil, pad, act; float slope;
+    int out_stride, out_off;            // output column of position q: q * out_stride + out_off
+    int Tq;                             // positions computed: q in [0, Tq)
+};
+
+int launch_conv1d(const ConvArgs& a, int B, hipStream_t st);
+int launch_stft(const float* s, int L, float* out, int M, int ld, size_t out_bs, int B, hipStream_t st);
+int launch_source_down(const float* x, int x_ld, size_t x_bs, int Tin, const float* w, const float* bias, float* y, int y_ld,
+                       size_t y_bs, int Tout, int Cout, int K, int stride, int pad, int B, hipStream_t st);
+int launch_reflect_left(float* x, int ld, int rows, hipStream_t st);
+int launch_istft(const float* x, int ld, size_t x_bs, int M, float* wav, int L, int B, hipStream_t st);
+int launch_f0_head(const float* x, int ld, size_t x_bs, int C, int T, const float* w, const float* bias, float* f0, int B,
+                   hipStream_t st);
+int launch_source(const float* f0, int T, double* prefix, const float* phase, const float* noise, uint64_t seed, const float* lw,
+                  const float* lb, float* s, int B, hipStream_t st);
+int launch_overwrite_head(float* s, int L, const float* cache, int n_cache, int B, hipStream_t st);
+
+void s3_set_error(const std::string& msg);
+#define S3_HIP_CHECK(expr)                                                                   \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) {                                                              \
+            s3_set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                 \
+            return 1;                                                                        \
+        }                                                                                    \
+    } while (0)
+#define S3_REQUIRE(cond, msg)                                                                \
+    do {                                                                                     \
+        if (!(cond)) { s3_set_error(std::string(msg) + " [" #cond "]"); return 1; }          \
+    } while (0)

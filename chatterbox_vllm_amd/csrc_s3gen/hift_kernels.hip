@@ -1,0 +1,376 @@
+// HiFT vocoder kernels for gfx950: fp32 convolutions on the f32-input matrix instruction, and the small kernels around them.
+//
+// Activations live in HBM as [batch][channel][time] fp32 (time contiguous, a row stride per buffer).  A convolution
+//     y[co][q] = bias[co] + sum_{ci, tap} W[co][ci][tap] * act(x[ci][q + tap * dil - pad])
+// is a matrix product with M = output channels (A operand = weights), N = time (B operand = activations) and
+// K = input channels x taps, on v_mfma_f32_32x32x2_f32: exact fp32 products and sums, 64 FLOP per clock and SIMD.
+//  * A workgroup of 4 waves owns 64 channels x 128 positions (or 32 x 256 for narrow layers); a wave owns 32 x 64 as two
+//    32 x 32 accumulators.
+//  * Input channels go through LDS 16 at a time: [16][positions + halo] with the activation function (Snake, leaky ReLU,
+//    ELU) applied on the way in, so every tap reads the same tile at a shifted column and a value's sine is taken once per
+//    workgroup, not once per tap.  Rows are 32 banks apart modulo 64, so the two half-waves of a B read (rows k and k+1)
+//    never meet in a bank.  The next 16 channels are loaded into registers before the current 16 are multiplied and
+//    written to the other LDS buffer after: one barrier per 16 channels.
+//  * Weights are read from memory in the instruction's own A layout (tile (32 channels, tap, 8 inputs) = 1 KiB, one
+//    16-byte load per lane = 4 k-steps), prefetched one tap ahead; every workgroup of a launch reads the same few MB,
+//    which stay in L2.
+//  * The epilogue adds bias and up to two residual tensors and either stores, or folds into the running mean of the three
+//    residual blocks of a stage.  Outputs may be strided (out_stride, out_off): a transposed convolution runs as one
+//    plain convolution per output phase.
+#include "hift_common.h"
+
+namespace {
+
+// periodic Hann window of 16 points (scipy get_window("hann", 16, fftbins=True) in fp32) and the 16th roots of unity
+__constant__ float c_hann[16] = {0.f, 0.038060233f, 0.146446615f, 0.308658272f, 0.5f, 0.691341698f, 0.853553414f, 0.961939752f,
+                                 1.f, 0.961939752f, 0.853553414f, 0.691341698f, 0.5f, 0.308658272f, 0.146446615f, 0.038060233f};
+__constant__ float c_cos16[16] = {1.f, 0.923879504f, 0.707106769f, 0.382683426f, 0.f, -0.382683426f, -0.707106769f, -0.923879504f,
+                                  -1.f, -0.923879504f, -0.707106769f, -0.382683426f, 0.f, 0.382683426f, 0.707106769f, 0.923879504f};
+__constant__ float c_sin16[16] = {0.f, 0.382683426f, 0.707106769f, 0.923879504f, 1.f, 0.923879504f, 0.707106769f, 0.382683426f,
+                                  0.f, -0.382683426f, -0.707106769f, -0.923879504f, -1.f, -0.923879504f, -0.707106769f, -0.382683426f};
+
+__device__ __forceinline__ float apply_act(float v, int act, float al, float inv, float slope) {
+    if (act == ACT_SNAKE) {
+        const float s = sinf(v * al);
+        return v + inv * (s * s);
+    }
+    if (act == ACT_LRELU) return v > 0.f ? v : v * slope;
+    if (act == ACT_ELU) return v > 0.f ? v : expf(v) - 1.0f;
+    return v;
+}
+
+template <int WCO, int WT>
+__global__ __launch_bounds__(256) void conv1d_kernel(ConvArgs a) {
+    constexpr int MT = 32 * WCO, NT = 64 * WT, XW = NT + 96, NCOL = (NT + CONV_MAX_HALO + 63) / 64;
+    static_assert(WCO * WT == 4 && XW % 64 == 32, "tile shape");
+    __shared__ float xs[2][CONV_CK][XW];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wco = w % WCO, wt = w / WCO;
+    const int q0 = blockIdx.x * NT, co0 = blockIdx.y * MT, b = blockIdx.z;
+    const float* __restrict__ xb = a.x + (size_t)b * a.x_bs;
+    const int span = NT + (a.K - 1) * a.dil;                 // columns of the tile that the taps touch
+    const int tin0 = q0 - a.pad;                             // input position of column 0
+
+    float raw[4][NCOL];
+    auto load_chunk = [&](int ci0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float* xr = xb + (size_t)(ci0 + w * 4 + r) * a.x_ld;
+#pragma unroll
+            for (int j = 0; j < NCOL; ++j) {
+                const int c = lane + 64 * j, t = tin0 + c;
+                raw[r][j] = (c < span && t >= 0 && t < a.Tin) ? xr[t] : 0.f;
+            }
+        }
+    };
+    auto store_chunk = [&](int buf, int ci0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float al = 0.f, inv = 0.f;
+            if (a.act == ACT_SNAKE) { al = a.alpha[ci0 + w * 4 + r]; inv = 1.0f / (al + 1e-9f); }
+#pragma unroll
+            for (int j = 0; j < NCOL; ++j) {
+                const int c = lane + 64 * j;
+                if (c < XW) xs[buf][w * 4 + r][c] = apply_act(raw[r][j], a.act, al, inv, a.slope);
+            }
+        }
+    };
+
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+    const int nchunk = a.Cin / CONV_CK, g8 = a.Cin / 8;
+    const int cb = (co0 >> 5) + wco;                          // this wave's block of 32 output channels
+    const bool live = cb * 32 < a.CoutPad;
+    const f32x4* __restrict__ wbase = reinterpret_cast<const f32x4*>(a.wt) + (size_t)(live ? cb : 0) * a.K * g8 * 64 + lane;
+
+    load_chunk(0);
+    store_chunk(0, 0);
+    __syncthreads();
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const int buf = ch & 1;
+        if (ch + 1 < nchunk) load_chunk((ch + 1) * CONV_CK);
+        if (live) {
+            const float* xrow = &xs[buf][lane >> 5][wt * 64 + (lane & 31)];
+            const f32x4* wp = wbase + (size_t)(ch * 2) * 64;
+            f32x4 A0 = wp[0], A1 = wp[64];
+            for (int tap = 0; tap < a.K; ++tap) {
+                f32x4 N0 = A0, N1 = A1;
+                if (tap + 1 < a.K) {
+                    const f32x4* np = wp + (size_t)(tap + 1) * g8 * 64;
+                    N0 = np[0];
+                    N1 = np[64];
+                }
+                const float* xp = xrow + tap * a.dil;
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+                    const float av = kk < 4 ? A0[kk & 3] : A1[kk & 3];
+                    const float b0 = xp[(2 * kk) * XW], b1 = xp[(2 * kk) * XW + 32];
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc1, 0, 0, 0);
+                }
+                A0 = N0;
+                A1 = N1;
+            }
+        }
+        if (ch + 1 < nchunk) store_chunk(buf ^ 1, (ch + 1) * CONV_CK);
+        __syncthreads();
+    }
+    if (!live) return;
+
+    // accumulator r of a lane: channel 8 (r / 4) + 4 (lane / 32) + r % 4 of the block, position lane % 32 of the sub-tile
+    const size_t ob = (size_t)b * a.y_bs;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int q = q0 + wt * 64 + half * 32 + (lane & 31);
+        const long long t = (long long)q * a.out_stride + a.out_off;
+        if (q >= a.Tq || t < 0 || t >= a.Tout) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = cb * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+            if (co >= a.Cout) continue;
+            float v = (half ? acc1[r] : acc0[r]) + a.bias[co];
+            const size_t o = ob + (size_t)co * a.y_ld + t;
+            if (a.res) v = v + a.res[o];
+            if (a.res2) v = a.res2[o] + v;
+            if (a.y) a.y[o] = v;
+            if (a.acc_mode == ACC_SET) a.acc[o] = v;
+            else if (a.acc_mode == ACC_ADD) a.acc[o] = a.acc[o] + v;
+            else if (a.acc_mode == ACC_ADD_DIV3) a.acc[o] = (a.acc[o] + v) / 3.0f;
+        }
+    }
+}
+
+// torch.stft(x, 16, 4, 16, hann, center=True, reflect): one thread per frame, 9 real and 9 imaginary outputs
+__global__ __launch_bounds__(256) void stft_kernel(const float* __restrict__ s, int L, float* __restrict__ out, int M, int ld,
+                                                   size_t out_bs) {
+    const int m = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (m >= M) return;
+    const float* sb = s + (size_t)b * L;
+    float x[16];
+#pragma unroll
+    for (int n = 0; n < 16; ++n) {
+        int i = 4 * m + n - 8;
+        i = i < 0 ? -i : (i >= L ? 2 * (L - 1) - i : i);
+        x[n] = sb[i] * c_hann[n];
+    }
+    float* ob = out + (size_t)b * out_bs + m;
+#pragma unroll
+    for (int f = 0; f < 9; ++f) {
+        float re = 0.f, im = 0.f;
+#pragma unroll
+        for (int n = 0; n < 16; ++n) {
+            re = fmaf(x[n], c_cos16[(f * n) & 15], re);
+            im = fmaf(x[n], c_sin16[(f * n) & 15], im);
+        }
+        ob[(size_t)f * ld] = re;
+        ob[(size_t)(9 + f) * ld] = -im;
+    }
+}
+
+// source_downs.i (hifigan.py:356-363): a strided convolution over the 18 STFT rows; one output channel per workgroup row
+__global__ __launch_bounds__(256) void source_down_kernel(const float* __restrict__ x, int x_ld, size_t x_bs, int Tin,
+                                                          const float* __restrict__ w, const float* __restrict__ bias,
+                                                          float* __restrict__ y, int y_ld, size_t y_bs, int Tout, int K,
+                                                          int stride, int pad) {
+    const int t = blockIdx.x * 256 + threadIdx.x, co = blockIdx.y, b = blockIdx.z;
+    if (t >= Tout) return;
+    const float* xb = x + (size_t)b * x_bs;
+    const float* wc = w + (size_t)co * 18 * K;
+    float acc = 0.f;
+    for (int ci = 0; ci < 18; ++ci) {
+        const float* xr = xb + (size_t)ci * x_ld;
+        for (int k = 0; k < K; ++k) {
+            const int i = t * stride + k - pad;
+            const float v = (i >= 0 && i < Tin) ? xr[i] : 0.f;
+            acc = fmaf(wc[ci * K + k], v, acc);
+        }
+    }
+    y[(size_t)b * y_bs + (size_t)co * y_ld + t] = acc + bias[co];
+}
+
+// nn.ReflectionPad1d((1, 0)) after the last upsampling (hifigan.py:421-422): the stage wrote its output one column to the
+// right; column 0 is the old column 1, which now sits in column 2
+__global__ void reflect_left_kernel(float* __restrict__ x, int ld, int rows) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r < rows) x[(size_t)r * ld] = x[(size_t)r * ld + 2];
+}
+
+// conv_post output [18][M] -> waveform: magnitude = min(exp(x[0:9]), 100), phase = sin(x[9:18]), inverse real DFT of
+// every frame, Hann window, overlap-add over the (up to) four frames that cover a sample, division by the overlap-added
+// squared window, 8 samples cut from both ends, clamp (hifigan.py:439-444, 404-410).  One thread per output sample.
+__global__ __launch_bounds__(256) void istft_kernel(const float* __restrict__ x, int ld, size_t x_bs, int M,
+                                                    float* __restrict__ wav, int L, float limit) {
+    const int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (i >= L) return;
+    const int n = i + 8;
+    const float* xb = x + (size_t)b * x_bs;
+    int m_lo = (n - 15 + 3) >> 2;
+    if (m_lo < 0) m_lo = 0;
+    int m_hi = n >> 2;
+    if (m_hi > M - 1) m_hi = M - 1;
+    float y = 0.f, env = 0.f;
+    for (int m = m_lo; m <= m_hi; ++m) {
+        const int j = n - 4 * m;
+        float fr = 0.f;
+#pragma unroll
+        for (int f = 0; f < 9; ++f) {
+            const float mag = fminf(expf(xb[(size_t)f * ld + m]), 100.0f);
+            const float ph = sinf(xb[(size_t)(9 + f) * ld + m]);
+            float sn, cs;
+            sincosf(ph, &sn, &cs);
+            const float re = mag * cs, im = mag * sn;
+            const float wgt = (f == 0 || f == 8) ? 1.0f : 2.0f;
+            fr += wgt * (re * c_cos16[(f * j) & 15]);
+            if (f != 0 && f != 8) fr -= wgt * (im * c_sin16[(f * j) & 15]);
+        }
+        const float wj = c_hann[j];
+        y += wj * (fr * (1.0f / 16.0f));
+        env += wj * wj;
+    }
+    y = y / env;
+    wav[(size_t)b * L + i] = fminf(fmaxf(y, -limit), limit);
+}
+
+// f0 = | w . elu(x[:, t]) + b |  (f0_predictor.py:50-55; the ELU is the last one of the condnet)
+__global__ __launch_bounds__(256) void f0_head_kernel(const float* __restrict__ x, int ld, size_t x_bs, int C, int T,
+                                                      const float* __restrict__ w, const float* __restrict__ bias,
+                                                      float* __restrict__ f0) {
+    const int t = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (t >= T) return;
+    const float* xb = x + (size_t)b * x_bs + t;
+    float acc = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const float v = xb[(size_t)c * ld];
+        acc = fmaf(w[c], v > 0.f ? v : expf(v) - 1.0f, acc);
+    }
+    f0[(size_t)b * T + t] = fabsf(acc + bias[0]);
+}
+
+// per (utterance, harmonic): the running sum of the per-sample phase increments at every frame start, in fp64
+__global__ void source_prefix_kernel(const float* __restrict__ f0, int T, double* __restrict__ prefix) {
+    const int b = blockIdx.x, h = threadIdx.x;
+    if (h >= S3HIFT_HARMONICS) return;
+    double run = 0.0;
+    for (int m = 0; m < T; ++m) {
+        prefix[((size_t)b * S3HIFT_HARMONICS + h) * T + m] = run;
+        const float inc = f0[(size_t)b * T + m] * (float)(h + 1) / 24000.0f;
+        run += 480.0 * (double)inc;
+    }
+}
+
+__device__ __forceinline__ uint32_t mix32(uint64_t z) {      // splitmix64 finaliser, upper half
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (uint32_t)(z >> 32);
+}
+__device__ __forceinline__ float unit_open(uint32_t u) { return ((float)(u >> 8) + 0.5f) * (1.0f / 16777216.0f); }   // (0, 1)
+
+// SineGen + SourceModuleHnNSF (hifigan.py:201-231, 267-283): one thread per output sample
+__global__ __launch_bounds__(256) void source_kernel(const float* __restrict__ f0, int T, const double* __restrict__ prefix,
+                                                     const float* __restrict__ phase, const float* __restrict__ noise,
+                                                     uint64_t seed, const float* __restrict__ lw, const float* __restrict__ lb,
+                                                     float* __restrict__ s) {
+    const int L = T * 480;
+    const int n = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (n >= L) return;
+    const int m = n / 480, j = n - m * 480;
+    const float f = f0[(size_t)b * T + m];
+    const float uv = f > 10.0f ? 1.0f : 0.0f;
+    const float noise_amp = uv * 0.003f + (1.0f - uv) * 0.1f / 3.0f;
+    float acc = 0.f;
+#pragma unroll
+    for (int h = 0; h < S3HIFT_HARMONICS; ++h) {
+        const float inc = f * (float)(h + 1) / 24000.0f;
+        const double cum = prefix[((size_t)b * S3HIFT_HARMONICS + h) * T + m] + (double)(j + 1) * (double)inc;
+        const float frac = (float)(cum - floor(cum));
+        const float theta = 6.283185307179586f * frac;
+        float ph = 0.f;
+        if (h > 0) {
+            ph = phase ? phase[b * S3HIFT_HARMONICS + h]
+                       : (2.0f * unit_open(mix32(seed ^ (0xA5A5ull << 48) ^ ((uint64_t)b << 8) ^ (uint64_t)h)) - 1.0f) * 3.14159265358979f;
+        }
+        float z;
+        if (noise) {
+            z = noise[((size_t)b * S3HIFT_HARMONICS + h) * L + n];
+        } else {                                            // Box-Muller on two counter-based uniforms
+            const uint64_t ctr = ((uint64_t)b * S3HIFT_HARMONICS + h) * (uint64_t)L + (uint64_t)n;
+            const float u1 = unit_open(mix32(seed + 2 * ctr)), u2 = unit_open(mix32(seed + 2 * ctr + 1));
+            z = sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+        }
+        const float sine = 0.1f * sinf(theta + ph);
+        acc = fmaf(sine * uv + noise_amp * z, lw[h], acc);
+    }
+    s[(size_t)b * L + n] = tanhf(acc + lb[0]);
+}
+
+__global__ void overwrite_head_kernel(float* __restrict__ s, int L, const float* __restrict__ cache, int n_cache) {
+    const int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (i < n_cache && i < L) s[(size_t)b * L + i] = cache[(size_t)b * n_cache + i];
+}
+
+}  // namespace
+
+int launch_conv1d(const ConvArgs& a, int B, hipStream_t st) {
+    S3_REQUIRE(a.Cin % CONV_CK == 0 && a.CoutPad % 32 == 0 && a.K >= 1, "conv1d: channel counts");
+    S3_REQUIRE((a.K - 1) * a.dil <= CONV_MAX_HALO, "conv1d: kernel span above the LDS tile's halo");
+    S3_REQUIRE(a.Tq >= 1 && B >= 1, "conv1d: empty launch");
+    if (a.CoutPad >= 64) {
+        hipLaunchKernelGGL((conv1d_kernel<2, 2>), dim3((a.Tq + 127) / 128, (a.CoutPad + 63) / 64, B), dim3(256), 0, st, a);
+    } else {
+        hipLaunchKernelGGL((conv1d_kernel<1, 4>), dim3((a.Tq + 255) / 256, 1, B), dim3(256), 0, st, a);
+    }
+    S3_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_stft(const float* s, int L, float* out, int M, int ld, size_t out_bs, int B, hipStream_t st) {
+    hipLaunchKernelGGL(stft_kernel, dim3((M + 255) / 256, B), dim3(256), 0, st, s, L, out, M, ld, out_bs);
+    S3_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_source_down(const float* x, int x_ld, size_t x_bs, int Tin, const float* w, const float* bias, float* y, int y_ld,
+                       size_t y_bs, int Tout, int Cout, int K, int stride, int pad, int B, hipStream_t st) {
+    hipLaunchKernelGGL(source_down_kernel, dim3((Tout + 255) / 256, Cout, B), dim3(256), 0, st, x, x_ld, x_bs, Tin, w, bias, y,
+                       y_ld, y_bs, Tout, K, stride, pad);
+    S3_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_reflect_left(float* x, int ld, int rows, hipStream_t st) {
+    hipLaunchKernelGGL(reflect_left_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, x, ld, rows);
+    S3_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_istft(const float* x, int ld, size_t x_bs, int M, float* wav, int L, int B, hipStream_t st) {
+    hipLaunchKernelGGL(istft_kernel, dim3((L + 255) / 256, B), dim3(256), 0, st, x, ld, x_bs, M, wav, L, 0.99f);
+    S3_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_f0_head(const float* x, int ld, size_t x_bs, int C, int T, const float* w, const float* bias, float* f0, int B,
+                   hipStream_t st) {
+    hipLaunchKernelGGL(f0_head_kernel, dim3((T + 255) / 256, B), dim3(256), 0, st, x, ld, x_bs, C, T, w, bias, f0);
+    S3_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_source(const float* f0, int T, double* prefix, const float* phase, const float* noise, uint64_t seed, const float* lw,
+                  const float* lb, float* s, int B, hipStream_t st) {
+    hipLaunchKernelGGL(source_prefix_kernel, dim3(B), dim3(64), 0, st, f0, T, prefix);
+    hipLaunchKernelGGL(source_kernel, dim3((T * 480 + 255) / 256, B), dim3(256), 0, st, f0, T, prefix, phase, noise, seed, lw,
+                       lb, s);
+    S3_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_overwrite_head(float* s, int L, const float* cache, int n_cache, int B, hipStream_t st) {
+    if (n_cache <= 0) return 0;
+    hipLaunchKernelGGL(overwrite_head_kernel, dim3((n_cache + 255) / 256, B), dim3(256), 0, st, s, L, cache, n_cache);
+    S3_HIP_CHECK(hipGetLastError());
+    return 0;
+}

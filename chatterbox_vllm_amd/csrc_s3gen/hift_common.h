@@ -25,14 +25,16 @@ struct ConvArgs {
     const float* res; const float* res2;
     float* acc; int acc_mode;
     int Cin, Cout, CoutPad, K, dil, pad, act; float slope;
-    int out_stride, out_off;            // output column of position q: q * out_stride + out_off
+    int out_stride, out_off;            // output column of position q: q * out_stride + out_off (+ phase, see phase_cout)
+    int phase_cout;                     // > 0: a transposed convolution with its output phases stacked as channels: row
+                                        //   co' = phase * phase_cout + co is channel co at column q * out_stride + phase + out_off
     int Tq;                             // positions computed: q in [0, Tq)
 };
 
 int launch_conv1d(const ConvArgs& a, int B, hipStream_t st);
 int launch_stft(const float* s, int L, float* out, int M, int ld, size_t out_bs, int B, hipStream_t st);
-int launch_source_down(const float* x, int x_ld, size_t x_bs, int Tin, const float* w, const float* bias, float* y, int y_ld,
-                       size_t y_bs, int Tout, int Cout, int K, int stride, int pad, int B, hipStream_t st);
+int launch_space_to_depth(const float* x, int x_ld, size_t x_bs, int Tin, int Cin, float* y, int y_ld, size_t y_bs, int Tq,
+                          int Cpad, int stride, int pad, int B, hipStream_t st);
 int launch_reflect_left(float* x, int ld, int rows, hipStream_t st);
 int launch_istft(const float* x, int ld, size_t x_bs, int M, float* wav, int L, int B, hipStream_t st);
 int launch_f0_head(const float* x, int ld, size_t x_bs, int C, int T, const float* w, const float* bias, float* f0, int B,

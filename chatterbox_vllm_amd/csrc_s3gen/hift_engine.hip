@@ -3,6 +3,7 @@
 #include "hift_common.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <map>
 #include <memory>
 #include <vector>
@@ -27,9 +28,11 @@ struct Conv {                        // one convolution in tile order on the dev
 struct ResBlock { Conv c1[3], c2[3]; float* a1[3] = {}; float* a2[3] = {}; int k = 0; };
 
 struct Stage {                       // one upsampling stage (hifigan.py:417-435)
-    Conv up[8];                      // one plain convolution per output phase of the transposed convolution
-    int up_taps[8] = {};
-    float *down_w = nullptr, *down_b = nullptr;
+    Conv up;                         // the transposed convolution as a plain one: output phases stacked as channels
+    int up_taps = 0;
+    Conv down;                       // source_downs.i after space-to-depth: two taps over stride x 18 channels
+    int down_cpad = 0;
+    float* SD = nullptr;             // its input: [down_cpad][L + 1]
     ResBlock src, res[3];
     int C = 0, L = 0, ld = 0;        // channels, length and row stride of this stage's tensors for the current call
     float *A = nullptr, *S0 = nullptr, *X = nullptr, *T1 = nullptr, *U0 = nullptr, *U1 = nullptr, *XS = nullptr;
@@ -69,7 +72,7 @@ int upload(s3hift* h, float** dst, const float* src, size_t n) {
 }
 
 // W[Cout][Cin][K] (host, row-major) -> tile order on the device
-int make_conv_from(s3hift* h, Conv* c, const float* w, const float* bias, int Cout, int Cin, int K) {
+int make_conv_from(s3hift* h, Conv* c, const float* w, const float* bias, int Cout, int Cin, int K, int n_bias = 0) {
     S3_REQUIRE(Cin % CONV_CK == 0, "convolution input channels must be a multiple of 16");
     c->Cin = Cin; c->Cout = Cout; c->K = K; c->CoutPad = (Cout + 31) / 32 * 32;
     const int g8 = Cin / 8, nb = c->CoutPad / 32;
@@ -84,7 +87,7 @@ int make_conv_from(s3hift* h, Conv* c, const float* w, const float* bias, int Co
                             t[((((size_t)cb * K + tap) * g8 + g) * 64 + lane) * 4 + j] = w[((size_t)co * Cin + ci) * K + tap];
                     }
     if (upload(h, &c->wt, t.data(), t.size())) return 1;
-    return upload(h, &c->bias, bias, Cout);
+    return upload(h, &c->bias, bias, n_bias ? n_bias : Cout);
 }
 
 int get(s3hift* h, const std::string& name, std::initializer_list<int64_t> shape, const Host** out) {
@@ -194,17 +197,26 @@ int run_decode(s3hift* h, const float* mel, const float* src, int B, int T, floa
         const int Lup = (Lin - 1) * u - 2 * p + kw;
         s.L = Lup + (last ? 1 : 0);
         const size_t bs = (size_t)s.C * s.ld;
-        for (int ph = 0; ph < u; ++ph) {                 // output column t = q u + ph - p, input position q - j for tap ph + j u
-            ConvArgs a = conv_args(s.up[ph], in, in_bs, in_ld, Lin, s.A, bs, s.ld, s.L);
+        {   // output column t = q u + phase - p takes input positions q - j through taps phase + j u: a plain convolution
+            // over q with up_taps taps, the phases stacked as output channels
+            ConvArgs a = conv_args(s.up, in, in_bs, in_ld, Lin, s.A, bs, s.ld, s.L);
             a.act = ACT_LRELU; a.slope = 0.1f;
-            a.pad = s.up_taps[ph] - 1;
-            a.out_stride = u; a.out_off = ph - p + (last ? 1 : 0);
-            a.Tq = (Lup - 1 + p - ph) / u + 1;
+            a.pad = s.up_taps - 1;
+            a.out_stride = u; a.out_off = -p + (last ? 1 : 0);
+            a.phase_cout = s.C;
+            a.Tq = (Lup - 1 + p) / u + 1;
             if (launch_conv1d(a, B, st)) return 1;
         }
         if (last && launch_reflect_left(s.A, s.ld, B * s.C, st)) return 1;      // batch stride = C * ld: rows are contiguous
-        if (launch_source_down(h->SST, sst_ld, sst_bs, M, s.down_w, s.down_b, s.S0, s.ld, bs, s.L, s.C, kDownK[i], kDownStride[i],
-                               kDownPad[i], B, st)) return 1;
+        {
+            const int sd = kDownStride[i];
+            const size_t sd_bs = (size_t)s.down_cpad * s.ld;
+            const int Tq = s.L + s.down.K - 1;
+            if (launch_space_to_depth(h->SST, sst_ld, sst_bs, M, kBins, s.SD, s.ld, sd_bs, Tq, s.down_cpad, sd, kDownPad[i], B, st))
+                return 1;
+            ConvArgs a = conv_args(s.down, s.SD, sd_bs, s.ld, Tq, s.S0, bs, s.ld, s.L);
+            if (launch_conv1d(a, B, st)) return 1;
+        }
         if (run_resblock(h, s, s.src, s.S0, s.X, s.A, ACC_NONE, B, st)) return 1;
         for (int j = 0; j < 3; ++j)
             if (run_resblock(h, s, s.res[j], s.X, nullptr, nullptr, j == 0 ? ACC_SET : (j == 1 ? ACC_ADD : ACC_ADD_DIV3), B, st))
@@ -290,19 +302,34 @@ extern "C" int s3hift_finalize(s3hift* h) {
         const Host *w, *b;
         const std::string n = "ups." + std::to_string(i);
         if (get(h, n + ".weight", {cin, cout, kw}, &w) || get(h, n + ".bias", {cout}, &b)) return 1;
-        for (int ph = 0; ph < u; ++ph) {
-            const int J = (kw - ph + u - 1) / u;
-            s.up_taps[ph] = J;
-            std::vector<float> wc((size_t)cout * cin * J);
-            for (int co = 0; co < cout; ++co)
-                for (int ci = 0; ci < cin; ++ci)
-                    for (int jp = 0; jp < J; ++jp)
-                        wc[((size_t)co * cin + ci) * J + jp] = w->v[((size_t)ci * cout + co) * kw + ph + (J - 1 - jp) * u];
-            if (make_conv_from(h, &s.up[ph], wc.data(), b->v.data(), cout, cin, J)) return 1;
+        {
+            const int J = (kw + u - 1) / u;              // taps of phase 0, the longest; shorter phases are zero-filled
+            s.up_taps = J;
+            std::vector<float> wc((size_t)u * cout * cin * J, 0.f);
+            for (int ph = 0; ph < u; ++ph)
+                for (int co = 0; co < cout; ++co)
+                    for (int ci = 0; ci < cin; ++ci)
+                        for (int jp = 0; jp < J; ++jp) {
+                            const int k = ph + (J - 1 - jp) * u;
+                            if (k < kw) wc[(((size_t)ph * cout + co) * cin + ci) * J + jp] = w->v[((size_t)ci * cout + co) * kw + k];
+                        }
+            if (make_conv_from(h, &s.up, wc.data(), b->v.data(), u * cout, cin, J, cout)) return 1;
         }
-        const std::string d = "source_downs." + std::to_string(i);
-        if (get(h, d + ".weight", {cout, kBins, kDownK[i]}, &w) || upload(h, &s.down_w, w->v.data(), w->v.size())) return 1;
-        if (get(h, d + ".bias", {cout}, &b) || upload(h, &s.down_b, b->v.data(), cout)) return 1;
+        {
+            // source_downs.i: w[cout][18][2 stride] (stride 1: [cout][18][1]) -> w'[cout][c * stride + r][j] = w[cout][c][j stride + r]
+            const int sd = kDownStride[i], kd = kDownK[i], taps = kd / sd;
+            s.down_cpad = (kBins * sd + CONV_CK - 1) / CONV_CK * CONV_CK;
+            const Host *dw, *db;
+            const std::string d = "source_downs." + std::to_string(i);
+            if (get(h, d + ".weight", {cout, kBins, kd}, &dw) || get(h, d + ".bias", {cout}, &db)) return 1;
+            std::vector<float> wc((size_t)cout * s.down_cpad * taps, 0.f);
+            for (int co = 0; co < cout; ++co)
+                for (int c = 0; c < kBins; ++c)
+                    for (int k = 0; k < kd; ++k)
+                        wc[((size_t)co * s.down_cpad + c * sd + k % sd) * taps + k / sd] = dw->v[((size_t)co * kBins + c) * kd + k];
+            if (make_conv_from(h, &s.down, wc.data(), db->v.data(), cout, s.down_cpad, taps)) return 1;
+            if (dalloc(h, reinterpret_cast<void**>(&s.SD), BT * s.down_cpad * s.ld * sizeof(float))) return 1;
+        }
         if (make_resblock(h, &s.src, "source_resblocks." + std::to_string(i), cout, kSrcResKernel[i])) return 1;
         for (int j = 0; j < 3; ++j)
             if (make_resblock(h, &s.res[j], "resblocks." + std::to_string(i * 3 + j), cout, kResKernel[j])) return 1;

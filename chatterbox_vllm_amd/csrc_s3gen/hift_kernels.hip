@@ -123,12 +123,16 @@ __global__ __launch_bounds__(256) void conv1d_kernel(ConvArgs a) {
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         const int q = q0 + wt * 64 + half * 32 + (lane & 31);
-        const long long t = (long long)q * a.out_stride + a.out_off;
-        if (q >= a.Tq || t < 0 || t >= a.Tout) continue;
+        if (q >= a.Tq) continue;
+        // a block of 32 rows never straddles two phases (phase_cout is a multiple of 32)
+        const int phase = a.phase_cout > 0 ? (cb * 32) / a.phase_cout : 0;
+        const long long t = (long long)q * a.out_stride + a.out_off + phase;
+        if (t < 0 || t >= a.Tout) continue;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int co = cb * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+            int co = cb * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
             if (co >= a.Cout) continue;
+            co -= phase * a.phase_cout;
             float v = (half ? acc1[r] : acc0[r]) + a.bias[co];
             const size_t o = ob + (size_t)co * a.y_ld + t;
             if (a.res) v = v + a.res[o];
@@ -168,25 +172,21 @@ __global__ __launch_bounds__(256) void stft_kernel(const float* __restrict__ s, 
     }
 }
 
-// source_downs.i (hifigan.py:356-363): a strided convolution over the 18 STFT rows; one output channel per workgroup row
-__global__ __launch_bounds__(256) void source_down_kernel(const float* __restrict__ x, int x_ld, size_t x_bs, int Tin,
-                                                          const float* __restrict__ w, const float* __restrict__ bias,
-                                                          float* __restrict__ y, int y_ld, size_t y_bs, int Tout, int K,
-                                                          int stride, int pad) {
-    const int t = blockIdx.x * 256 + threadIdx.x, co = blockIdx.y, b = blockIdx.z;
-    if (t >= Tout) return;
-    const float* xb = x + (size_t)b * x_bs;
-    const float* wc = w + (size_t)co * 18 * K;
-    float acc = 0.f;
-    for (int ci = 0; ci < 18; ++ci) {
-        const float* xr = xb + (size_t)ci * x_ld;
-        for (int k = 0; k < K; ++k) {
-            const int i = t * stride + k - pad;
-            const float v = (i >= 0 && i < Tin) ? xr[i] : 0.f;
-            acc = fmaf(wc[ci * K + k], v, acc);
-        }
+// source_downs.i (hifigan.py:356-363) is a strided convolution over the 18 STFT rows (kernel 2 x stride).  Here the stride
+// is folded into the channels first: y[c * stride + r][q] = x[c][q * stride + r - pad] (zero outside, zero rows up to Cpad),
+// after which the layer is a plain two-tap convolution over stride x 18 channels for the matrix kernel.
+__global__ __launch_bounds__(256) void space_to_depth_kernel(const float* __restrict__ x, int x_ld, size_t x_bs, int Tin, int Cin,
+                                                             float* __restrict__ y, int y_ld, size_t y_bs, int Tq, int stride,
+                                                             int pad) {
+    const int q = blockIdx.x * 256 + threadIdx.x, cp = blockIdx.y, b = blockIdx.z;
+    if (q >= Tq) return;
+    const int c = cp / stride, r = cp - c * stride;
+    float v = 0.f;
+    if (c < Cin) {
+        const int i = q * stride + r - pad;
+        if (i >= 0 && i < Tin) v = x[(size_t)b * x_bs + (size_t)c * x_ld + i];
     }
-    y[(size_t)b * y_bs + (size_t)co * y_ld + t] = acc + bias[co];
+    y[(size_t)b * y_bs + (size_t)cp * y_ld + q] = v;
 }
 
 // nn.ReflectionPad1d((1, 0)) after the last upsampling (hifigan.py:421-422): the stage wrote its output one column to the
@@ -317,6 +317,7 @@ int launch_conv1d(const ConvArgs& a, int B, hipStream_t st) {
     S3_REQUIRE(a.Cin % CONV_CK == 0 && a.CoutPad % 32 == 0 && a.K >= 1, "conv1d: channel counts");
     S3_REQUIRE((a.K - 1) * a.dil <= CONV_MAX_HALO, "conv1d: kernel span above the LDS tile's halo");
     S3_REQUIRE(a.Tq >= 1 && B >= 1, "conv1d: empty launch");
+    S3_REQUIRE(a.phase_cout % 32 == 0, "conv1d: stacked phases must be whole blocks of 32 channels");
     if (a.CoutPad >= 64) {
         hipLaunchKernelGGL((conv1d_kernel<2, 2>), dim3((a.Tq + 127) / 128, (a.CoutPad + 63) / 64, B), dim3(256), 0, st, a);
     } else {
@@ -332,10 +333,10 @@ int launch_stft(const float* s, int L, float* out, int M, int ld, size_t out_bs,
     return 0;
 }
 
-int launch_source_down(const float* x, int x_ld, size_t x_bs, int Tin, const float* w, const float* bias, float* y, int y_ld,
-                       size_t y_bs, int Tout, int Cout, int K, int stride, int pad, int B, hipStream_t st) {
-    hipLaunchKernelGGL(source_down_kernel, dim3((Tout + 255) / 256, Cout, B), dim3(256), 0, st, x, x_ld, x_bs, Tin, w, bias, y,
-                       y_ld, y_bs, Tout, K, stride, pad);
+int launch_space_to_depth(const float* x, int x_ld, size_t x_bs, int Tin, int Cin, float* y, int y_ld, size_t y_bs, int Tq,
+                          int Cpad, int stride, int pad, int B, hipStream_t st) {
+    hipLaunchKernelGGL(space_to_depth_kernel, dim3((Tq + 255) / 256, Cpad, B), dim3(256), 0, st, x, x_ld, x_bs, Tin, Cin, y, y_ld,
+                       y_bs, Tq, stride, pad);
     S3_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -215,6 +215,63 @@ def make_engine(cfg, sd, conc, paired, device, args, quantization, policy, uncon
                     prefix_sharing=not args.no_prefix_sharing)
 
 
+FP32_MFMA_PEAK_TFLOPS = 157.3     # v_mfma_f32_32x32x2_f32, 64 FLOP per clock and SIMD, 1024 SIMDs at 2.4 GHz
+
+
+def vocoder_leg(device, batch=8, frames=500, iters=5):
+    """The token -> waveform side's last stage: HiFT vocoder decode() (mel + source -> 24 kHz waveform, fp32) for `batch`
+    utterances of `frames` mel frames (10 s each at 500), inputs resident in HBM.  Its roofline is the fp32 matrix
+    pipe: algorithmic FLOP of the convolutions (hift_weights.decode_flop) over the HIP-event time of the whole call on
+    the call's stream, so the small kernels around the convolutions count against it.  The CPU figure is the oracle
+    (torch fp32, the reference's own arithmetic) on the same batch, once."""
+    from chatterbox_vllm_amd import hift_weights as HW
+    from chatterbox_vllm_amd.hift import HiFTGenerator
+    sd = HW.synthetic_state_dict()
+    gen = HiFTGenerator(sd, max_batch=batch, max_frames=frames, device=device)
+    mel = HW.synthetic_mel(frames, seed=3, batch=batch).to(f"cuda:{device}")
+    src = gen.source(gen.f0_predictor(mel), seed=1)
+    gen.decode(mel, src)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        gen.decode(mel, src)
+    torch.cuda.synchronize(device)
+    wall = (time.perf_counter() - t0) / iters
+    gen.set_timing(True)
+    ev = []
+    for _ in range(iters):
+        gen.decode(mel, src)
+        ev.append(gen.last_timing())
+    gen.set_timing(False)
+    ev_ms = sum(e[5] for e in ev) / len(ev)
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        gen.inference(mel, seed=2)
+    torch.cuda.synchronize(device)
+    wall_inf = (time.perf_counter() - t0) / iters
+    gen.shutdown()
+    pre, stages, post = HW.decode_flop(frames)
+    flop = batch * (pre + sum(stages) + post)
+    achieved = flop / (ev_ms * 1e-3) / 1e12
+    rec = {"workload": f"S3Gen HiFT vocoder, decode() of {batch} utterances x {frames} mel frames ({frames * 0.02:.0f} s each), seeded synthetic weights",
+           "metric": "audio seconds per second", "value": round(batch * frames * 0.02 / wall, 1), "unit": "audio s/s",
+           "ms_per_step": round(wall * 1e3, 3), "inference_value": round(batch * frames * 0.02 / wall_inf, 1), "dtype": "f32",
+           "roofline": {"bound": "mfma", "kernel": "conv1d_kernel (74 launches of a call)", "achieved": round(achieved, 2),
+                        "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                        "traffic": None, "event_ms_per_call": round(ev_ms, 3), "algorithmic_gflop_per_call": round(flop / 1e9, 1),
+                        "stage_ms": [round(sum(e[i] for e in ev) / len(ev), 3) for i in range(5)]}}
+    from oracle import hift_oracle as HO
+    w = HO.fold_weight_norm(sd)
+    mel_c, src_c = mel.cpu(), src.cpu()
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    t0 = time.perf_counter()
+    HO.decode(w, mel_c, src_c)
+    dt = time.perf_counter() - t0
+    rec["cpu_baseline"] = {"value": round(batch * frames * 0.02 / dt, 2), "unit": "audio s/s", "cores": torch.get_num_threads(),
+                           "kind": "port", "sample": f"one decode() of the same {batch} x {frames} frames, torch fp32, {dt:.1f} s"}
+    return rec
+
+
 def extra_leg(args, device, sd_cache, workload, conc, quantization, repeat, label):
     """One short leg of another BASELINE configuration on this GPU: one warm-up pass, one timed pass, one event-timed
     pass.  Returns the record that goes under "other_configs"."""
@@ -479,6 +536,7 @@ def main():
             extra_leg(args, local_rank, cache, "multilingual", 64, "none", 1,
                       "configs[4]: multilingual vocabulary, fr + zh mixed, 64 slots, 4 voices"),
         ]
+        result["vocoder"] = vocoder_leg(local_rank)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.rehearse:   # the CPU leg is timed on the one-GPU run only
         cb, cpu_ids, sub = cpu_baseline(cfg, sd, job, conds, paired=paired)

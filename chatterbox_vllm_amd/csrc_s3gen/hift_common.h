@@ -29,6 +29,9 @@ struct ConvArgs {
     int phase_cout;                     // > 0: a transposed convolution with its output phases stacked as channels: row
                                         //   co' = phase * phase_cout + co is channel co at column q * out_stride + phase + out_off
     int Tq;                             // positions computed: q in [0, Tq)
+#ifdef S3_TIMELINE
+    long long* timeline;                // tools/conv_probe: cycle stamps, 64 per wave
+#endif
 };
 
 int launch_conv1d(const ConvArgs& a, int B, hipStream_t st);

@@ -29,20 +29,40 @@ __constant__ float c_cos16[16] = {1.f, 0.923879504f, 0.707106769f, 0.382683426f,
 __constant__ float c_sin16[16] = {0.f, 0.382683426f, 0.707106769f, 0.923879504f, 1.f, 0.923879504f, 0.707106769f, 0.382683426f,
                                   0.f, -0.382683426f, -0.707106769f, -0.923879504f, -1.f, -0.923879504f, -0.707106769f, -0.382683426f};
 
-__device__ __forceinline__ float apply_act(float v, int act, float al, float inv, float slope) {
-    if (act == ACT_SNAKE) {
-        const float s = sinf(v * al);
-        return v + inv * (s * s);
-    }
-    if (act == ACT_LRELU) return v > 0.f ? v : v * slope;
-    if (act == ACT_ELU) return v > 0.f ? v : expf(v) - 1.0f;
-    return v;
+// sin(t)^2 for the Snake activation.  The sign of the sine does not matter, so after reducing t by multiples of pi/2
+// (three-part constant, exact products for |t| < 8192) only the parity of the multiple selects between the sine and the
+// cosine polynomial of the remainder (|r| <= pi/4; coefficients of the classic single-precision kernels, error below
+// 1e-7).  Larger arguments, which a trained vocoder does not produce, take the library routine out of line.
+__device__ __noinline__ float sin_sq_slow(float t) {
+    const float s = sinf(t);
+    return s * s;
+}
+__device__ __forceinline__ float sin_sq(float t) {
+    if (__builtin_expect(fabsf(t) > 8192.0f, 0)) return sin_sq_slow(t);
+    const float k = rintf(t * 0.636619772f);
+    float r = fmaf(k, -1.5703125f, t);
+    r = fmaf(k, -4.837512969970703125e-4f, r);
+    r = fmaf(k, -7.54978995489188216e-8f, r);
+    const float z = r * r;
+    const float sp = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, r, r);
+    const float cp = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f), z * z,
+                          fmaf(-0.5f, z, 1.0f));
+    const float v = ((int)k & 1) ? cp : sp;
+    return v * v;
 }
 
-template <int WCO, int WT>
+template <int ACT>
+__device__ __forceinline__ float apply_act(float v, float al, float inv, float slope) {
+    if constexpr (ACT == ACT_SNAKE) return fmaf(inv, sin_sq(v * al), v);
+    else if constexpr (ACT == ACT_LRELU) return v > 0.f ? v : v * slope;
+    else if constexpr (ACT == ACT_ELU) return v > 0.f ? v : expf(v) - 1.0f;
+    else return v;
+}
+
+template <int WCO, int WT, int ACT>
 __global__ __launch_bounds__(256) void conv1d_kernel(ConvArgs a) {
     constexpr int MT = 32 * WCO, NT = 64 * WT, XW = NT + 96, NCOL = (NT + CONV_MAX_HALO + 63) / 64;
-    static_assert(WCO * WT == 4 && XW % 64 == 32, "tile shape");
+    static_assert(WCO * WT == 4 && XW % 64 == 32 && NCOL * 64 <= XW, "tile shape");
     __shared__ float xs[2][CONV_CK][XW];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wco = w % WCO, wt = w / WCO;
@@ -51,31 +71,43 @@ __global__ __launch_bounds__(256) void conv1d_kernel(ConvArgs a) {
     const int span = NT + (a.K - 1) * a.dil;                 // columns of the tile that the taps touch
     const int tin0 = q0 - a.pad;                             // input position of column 0
 
+    // this lane's columns of a tile row: input position (clamped for the load, the value zeroed when outside)
+    int tcl[NCOL];
+    bool ok[NCOL];
+#pragma unroll
+    for (int j = 0; j < NCOL; ++j) {
+        const int c = lane + 64 * j, t = tin0 + c;
+        ok[j] = c < span && t >= 0 && t < a.Tin;
+        tcl[j] = t < 0 ? 0 : (t >= a.Tin ? a.Tin - 1 : t);
+    }
     float raw[4][NCOL];
     auto load_chunk = [&](int ci0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float* xr = xb + (size_t)(ci0 + w * 4 + r) * a.x_ld;
 #pragma unroll
-            for (int j = 0; j < NCOL; ++j) {
-                const int c = lane + 64 * j, t = tin0 + c;
-                raw[r][j] = (c < span && t >= 0 && t < a.Tin) ? xr[t] : 0.f;
-            }
+            for (int j = 0; j < NCOL; ++j) raw[r][j] = xr[tcl[j]];
         }
     };
     auto store_chunk = [&](int buf, int ci0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float al = 0.f, inv = 0.f;
-            if (a.act == ACT_SNAKE) { al = a.alpha[ci0 + w * 4 + r]; inv = 1.0f / (al + 1e-9f); }
+            if constexpr (ACT == ACT_SNAKE) { al = a.alpha[ci0 + w * 4 + r]; inv = 1.0f / (al + 1e-9f); }
 #pragma unroll
-            for (int j = 0; j < NCOL; ++j) {
-                const int c = lane + 64 * j;
-                if (c < XW) xs[buf][w * 4 + r][c] = apply_act(raw[r][j], a.act, al, inv, a.slope);
-            }
+            for (int j = 0; j < NCOL; ++j)
+                xs[buf][w * 4 + r][lane + 64 * j] = ok[j] ? apply_act<ACT>(raw[r][j], al, inv, a.slope) : 0.f;
         }
     };
 
+#ifdef S3_TIMELINE
+    long long* tl = a.timeline ? a.timeline + ((size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 4 + w) * 64 : nullptr;
+    int tli = 0;
+#define S3_STAMP() do { if (tl && lane == 0 && tli < 64) tl[tli++] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define S3_STAMP() do { } while (0)
+#endif
+    S3_STAMP();
     f32x16 acc0, acc1;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
@@ -85,22 +117,23 @@ __global__ __launch_bounds__(256) void conv1d_kernel(ConvArgs a) {
     const f32x4* __restrict__ wbase = reinterpret_cast<const f32x4*>(a.wt) + (size_t)(live ? cb : 0) * a.K * g8 * 64 + lane;
 
     load_chunk(0);
+    f32x4 A0 = wbase[0], A1 = wbase[64];                      // weights of (chunk 0, tap 0); then always one step ahead
     store_chunk(0, 0);
     __syncthreads();
     for (int ch = 0; ch < nchunk; ++ch) {
         const int buf = ch & 1;
-        if (ch + 1 < nchunk) load_chunk((ch + 1) * CONV_CK);
+        const bool more = ch + 1 < nchunk;
+        S3_STAMP();
+        if (more) load_chunk((ch + 1) * CONV_CK);
+        S3_STAMP();
         if (live) {
             const float* xrow = &xs[buf][lane >> 5][wt * 64 + (lane & 31)];
-            const f32x4* wp = wbase + (size_t)(ch * 2) * 64;
-            f32x4 A0 = wp[0], A1 = wp[64];
             for (int tap = 0; tap < a.K; ++tap) {
-                f32x4 N0 = A0, N1 = A1;
-                if (tap + 1 < a.K) {
-                    const f32x4* np = wp + (size_t)(tap + 1) * g8 * 64;
-                    N0 = np[0];
-                    N1 = np[64];
-                }
+                // the step after (ch, tap) is (ch, tap + 1), or (ch + 1, 0); the last step re-reads its own tile
+                const bool wrap = tap + 1 == a.K;
+                const int nch = wrap ? (more ? ch + 1 : ch) : ch, ntap = wrap ? (more ? 0 : tap) : tap + 1;
+                const f32x4* np = wbase + ((size_t)ntap * g8 + nch * 2) * 64;
+                const f32x4 N0 = np[0], N1 = np[64];
                 const float* xp = xrow + tap * a.dil;
 #pragma unroll
                 for (int kk = 0; kk < 8; ++kk) {
@@ -113,28 +146,32 @@ __global__ __launch_bounds__(256) void conv1d_kernel(ConvArgs a) {
                 A1 = N1;
             }
         }
-        if (ch + 1 < nchunk) store_chunk(buf ^ 1, (ch + 1) * CONV_CK);
+        S3_STAMP();
+        if (more) store_chunk(buf ^ 1, (ch + 1) * CONV_CK);
+        S3_STAMP();
         __syncthreads();
     }
+    S3_STAMP();
     if (!live) return;
 
-    // accumulator r of a lane: channel 8 (r / 4) + 4 (lane / 32) + r % 4 of the block, position lane % 32 of the sub-tile
+    // accumulator r of a lane: channel 8 (r / 4) + 4 (lane / 32) + r % 4 of the block, position lane % 32 of the sub-tile;
+    // a block of 32 rows never straddles two phases (phase_cout is a multiple of 32)
+    const int phase = a.phase_cout > 0 ? (cb * 32) / a.phase_cout : 0;
+    const int co_base = cb * 32 + 4 * (lane >> 5) - phase * a.phase_cout;
+    const int co_lim = a.Cout - phase * a.phase_cout;        // co_base + 8 (r / 4) + r % 4 must stay below
     const size_t ob = (size_t)b * a.y_bs;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         const int q = q0 + wt * 64 + half * 32 + (lane & 31);
-        if (q >= a.Tq) continue;
-        // a block of 32 rows never straddles two phases (phase_cout is a multiple of 32)
-        const int phase = a.phase_cout > 0 ? (cb * 32) / a.phase_cout : 0;
         const long long t = (long long)q * a.out_stride + a.out_off + phase;
-        if (t < 0 || t >= a.Tout) continue;
+        if (q >= a.Tq || t < 0 || t >= a.Tout) continue;
+        const unsigned o0 = (unsigned)co_base * (unsigned)a.y_ld + (unsigned)t;   // inside the utterance: below 2^32
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            int co = cb * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
-            if (co >= a.Cout) continue;
-            co -= phase * a.phase_cout;
-            float v = (half ? acc1[r] : acc0[r]) + a.bias[co];
-            const size_t o = ob + (size_t)co * a.y_ld + t;
+            const int dco = 8 * (r >> 2) + (r & 3);
+            if (co_base + dco >= co_lim) continue;
+            float v = (half ? acc1[r] : acc0[r]) + a.bias[co_base + dco];
+            const size_t o = ob + o0 + (unsigned)dco * (unsigned)a.y_ld;
             if (a.res) v = v + a.res[o];
             if (a.res2) v = a.res2[o] + v;
             if (a.y) a.y[o] = v;
@@ -143,6 +180,7 @@ __global__ __launch_bounds__(256) void conv1d_kernel(ConvArgs a) {
             else if (a.acc_mode == ACC_ADD_DIV3) a.acc[o] = (a.acc[o] + v) / 3.0f;
         }
     }
+    S3_STAMP();
 }
 
 // torch.stft(x, 16, 4, 16, hann, center=True, reflect): one thread per frame, 9 real and 9 imaginary outputs
@@ -317,12 +355,23 @@ int launch_conv1d(const ConvArgs& a, int B, hipStream_t st) {
     S3_REQUIRE(a.Cin % CONV_CK == 0 && a.CoutPad % 32 == 0 && a.K >= 1, "conv1d: channel counts");
     S3_REQUIRE((a.K - 1) * a.dil <= CONV_MAX_HALO, "conv1d: kernel span above the LDS tile's halo");
     S3_REQUIRE(a.Tq >= 1 && B >= 1, "conv1d: empty launch");
+    S3_REQUIRE((long long)a.Cout * a.y_ld < (1LL << 32), "conv1d: utterance above 2^32 elements");
     S3_REQUIRE(a.phase_cout % 32 == 0, "conv1d: stacked phases must be whole blocks of 32 channels");
-    if (a.CoutPad >= 64) {
-        hipLaunchKernelGGL((conv1d_kernel<2, 2>), dim3((a.Tq + 127) / 128, (a.CoutPad + 63) / 64, B), dim3(256), 0, st, a);
-    } else {
-        hipLaunchKernelGGL((conv1d_kernel<1, 4>), dim3((a.Tq + 255) / 256, 1, B), dim3(256), 0, st, a);
+    const bool wide = a.CoutPad >= 64;
+    const dim3 grid = wide ? dim3((a.Tq + 127) / 128, (a.CoutPad + 63) / 64, B) : dim3((a.Tq + 255) / 256, 1, B);
+#define S3_CONV_LAUNCH(ACT)                                                                                   \
+    do {                                                                                                      \
+        if (wide) hipLaunchKernelGGL((conv1d_kernel<2, 2, ACT>), grid, dim3(256), 0, st, a);                  \
+        else hipLaunchKernelGGL((conv1d_kernel<1, 4, ACT>), grid, dim3(256), 0, st, a);                       \
+    } while (0)
+    switch (a.act) {
+        case ACT_NONE: S3_CONV_LAUNCH(ACT_NONE); break;
+        case ACT_SNAKE: S3_CONV_LAUNCH(ACT_SNAKE); break;
+        case ACT_LRELU: S3_CONV_LAUNCH(ACT_LRELU); break;
+        case ACT_ELU: S3_CONV_LAUNCH(ACT_ELU); break;
+        default: S3_REQUIRE(false, "conv1d: unknown activation");
     }
+#undef S3_CONV_LAUNCH
     S3_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -117,3 +117,23 @@ def fold_weight_norm(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         elif not k.endswith(suffix_g):
             out[k] = v.float().contiguous()
     return out
+
+
+def decode_flop(n_frames: int):
+    """Algorithmic FLOP (2 x multiply-adds) of the convolutions of ``HiFTGenerator.decode`` for one utterance of
+    ``n_frames`` mel frames: (conv_pre, [stage 0, stage 1, stage 2], conv_post).  A stage = its transposed convolution
+    (every input position meets every tap), source_downs, the source residual block and the three residual blocks."""
+    pre = 2 * MEL * BASE * 7 * n_frames
+    stages, length = [], n_frames
+    for i in range(3):
+        cin, c = BASE >> i, BASE >> (i + 1)
+        out_len = length * UP_RATES[i] + (1 if i == 2 else 0)
+        f = 2 * cin * c * UP_KERNELS[i] * length
+        f += 2 * (N_FFT + 2) * c * SRC_DOWN[i][0] * out_len
+        f += 6 * 2 * c * c * SRC_RES_KERNELS[i] * out_len
+        for rk in RES_KERNELS:
+            f += 6 * 2 * c * c * rk * out_len
+        stages.append(f)
+        length = out_len
+    post = 2 * (BASE >> 3) * (N_FFT + 2) * 7 * length
+    return pre, stages, post

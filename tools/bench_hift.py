@@ -16,26 +16,6 @@ from chatterbox_vllm_amd import hift_weights as HW          # noqa: E402
 from chatterbox_vllm_amd.hift import HiFTGenerator           # noqa: E402
 
 
-def decode_flop(T):
-    """2 x multiply-adds of every convolution of decode() for T mel frames (one utterance), by stage."""
-    pre = 2 * 80 * 512 * 7 * T
-    stages, L = [], T
-    for i in range(3):
-        cin, c = 512 >> i, 512 >> (i + 1)
-        u, kw = HW.UP_RATES[i], HW.UP_KERNELS[i]
-        Lout = L * u + (1 if i == 2 else 0)
-        f = 2 * cin * c * kw * L                                     # transposed convolution: every input meets every tap
-        k, s, _ = HW.SRC_DOWN[i]
-        f += 2 * 18 * c * k * Lout
-        f += 6 * 2 * c * c * HW.SRC_RES_KERNELS[i] * Lout
-        for rk in HW.RES_KERNELS:
-            f += 6 * 2 * c * c * rk * Lout
-        stages.append(f)
-        L = Lout
-    post = 2 * 64 * 18 * 7 * L
-    return pre, stages, post
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=4)
@@ -63,7 +43,7 @@ def main():
         gen.inference(mel, seed=2)
     torch.cuda.synchronize()
     dt_inf = (time.perf_counter() - t0) / args.iters
-    pre, stages, post = decode_flop(T)
+    pre, stages, post = HW.decode_flop(T)
     flop = B * (pre + sum(stages) + post)
     out = {"batch": B, "frames": T, "audio_s_per_call": B * T * 0.02, "decode_ms": round(dt * 1e3, 3),
            "inference_ms": round(dt_inf * 1e3, 3), "audio_s_per_s": round(B * T * 0.02 / dt, 1),

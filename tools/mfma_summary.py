@@ -7,7 +7,8 @@ For every kernel: dispatches, mean duration, and
   mfma_util      = sum(SQ_VALU_MFMA_BUSY_CYCLES) / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs): the share of SIMD-cycles in which
                    the matrix pipe was busy while the dispatch ran (rocprofv3 reports GRBM_GUI_ACTIVE summed over the 8 XCDs);
   tflops         = SQ_INSTS_VALU_MFMA_MOPS_BF16 * 512 flop / duration (dense bf16 peak of the chip: ~2500 TFLOP/s);
-  frac_of_peak   = tflops / 2500."""
+  frac_of_peak   = tflops / 2500.
+With SQ_INSTS_VALU_MFMA_MOPS_F32 in the pass (the fp32 vocoder), the same against the 157.3 TFLOP/s fp32 matrix peak."""
 import csv, glob, json, sys
 from collections import defaultdict
 
@@ -19,7 +20,7 @@ n = defaultdict(int)
 seen = set()
 for f in cc:
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0][:72]
+        k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0][:72]
         val[k][r["Counter_Name"]] += float(r["Counter_Value"])
         key = (r.get("Dispatch_Id"), k)
         if key not in seen:
@@ -29,7 +30,7 @@ dur = defaultdict(float)
 nd = defaultdict(int)
 for f in kt:
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0][:72]
+        k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0][:72]
         dur[k] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
         nd[k] += 1
 out = {}
@@ -45,6 +46,10 @@ for k in sorted(val, key=lambda k: -val[k].get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0))
         rec["mean_us_under_profiler"] = round(dur[k] / nd[k] / 1e3, 2)
         rec["tflops"] = round(mops * 512.0 / s / 1e12, 2)
         rec["frac_of_dense_bf16_peak"] = round(mops * 512.0 / s / 1e12 / 2500.0, 4)
+        f32 = v.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0.0)
+        if f32 > 0:                                       # fp32-input matrix instructions (peak 157.3 TFLOP/s)
+            rec["tflops_f32"] = round(f32 * 512.0 / s / 1e12, 2)
+            rec["frac_of_f32_matrix_peak"] = round(f32 * 512.0 / s / 1e12 / 157.3, 4)
     out[k] = rec
 json.dump({"counters": "SQ_VALU_MFMA_BUSY_CYCLES, SQ_INSTS_VALU_MFMA_MOPS_BF16 (x512 flop), GRBM_GUI_ACTIVE (sum over 8 XCDs)",
            "kernels": out}, sys.stdout, indent=1)

@@ -152,32 +152,73 @@ __global__ __launch_bounds__(256) void conv1d_kernel(ConvArgs a) {
         __syncthreads();
     }
     S3_STAMP();
-    if (!live) return;
-
-    // accumulator r of a lane: channel 8 (r / 4) + 4 (lane / 32) + r % 4 of the block, position lane % 32 of the sub-tile;
-    // a block of 32 rows never straddles two phases (phase_cout is a multiple of 32)
-    const int phase = a.phase_cout > 0 ? (cb * 32) / a.phase_cout : 0;
-    const int co_base = cb * 32 + 4 * (lane >> 5) - phase * a.phase_cout;
-    const int co_lim = a.Cout - phase * a.phase_cout;        // co_base + 8 (r / 4) + r % 4 must stay below
     const size_t ob = (size_t)b * a.y_bs;
+    // one output element: bias, residuals, store, running mean of the stage (same operations in both epilogue forms)
+    auto finish = [&](float v, int co, size_t o) {
+        v = v + a.bias[co];
+        if (a.res) v = v + a.res[o];
+        if (a.res2) v = a.res2[o] + v;
+        if (a.y) a.y[o] = v;
+        if (a.acc_mode == ACC_SET) a.acc[o] = v;
+        else if (a.acc_mode == ACC_ADD) a.acc[o] = a.acc[o] + v;
+        else if (a.acc_mode == ACC_ADD_DIV3) a.acc[o] = (a.acc[o] + v) / 3.0f;
+    };
+    // accumulator r of a lane: channel 8 (r / 4) + 4 (lane / 32) + r % 4 of the block, position lane % 32 of the sub-tile
+    if (a.out_stride == 1 && a.phase_cout == 0 && a.out_off >= 0 && ((a.y_ld | a.out_off) & 3) == 0) {
+        // contiguous, 16-byte aligned rows: each 32 x 32 accumulator goes through this wave's 5 KiB of the (now free) tile
+        // buffer and comes back as four 16-byte pieces per lane, 8 rows x 128 bytes per store instruction
+        float* ep = &xs[0][0][0] + w * (32 * 40);
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        const int q = q0 + wt * 64 + half * 32 + (lane & 31);
-        const long long t = (long long)q * a.out_stride + a.out_off + phase;
-        if (q >= a.Tq || t < 0 || t >= a.Tout) continue;
-        const unsigned o0 = (unsigned)co_base * (unsigned)a.y_ld + (unsigned)t;   // inside the utterance: below 2^32
+        for (int half = 0; half < 2; ++half) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int dco = 8 * (r >> 2) + (r & 3);
-            if (co_base + dco >= co_lim) continue;
-            float v = (half ? acc1[r] : acc0[r]) + a.bias[co_base + dco];
-            const size_t o = ob + o0 + (unsigned)dco * (unsigned)a.y_ld;
-            if (a.res) v = v + a.res[o];
-            if (a.res2) v = a.res2[o] + v;
-            if (a.y) a.y[o] = v;
-            if (a.acc_mode == ACC_SET) a.acc[o] = v;
-            else if (a.acc_mode == ACC_ADD) a.acc[o] = a.acc[o] + v;
-            else if (a.acc_mode == ACC_ADD_DIV3) a.acc[o] = (a.acc[o] + v) / 3.0f;
+            for (int r = 0; r < 16; ++r)
+                ep[(8 * (r >> 2) + 4 * (lane >> 5) + (r & 3)) * 40 + (lane & 31)] = half ? acc1[r] : acc0[r];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = i * 8 + (lane >> 3), c4 = (lane & 7) * 4;
+                const f32x4 v4 = *reinterpret_cast<const f32x4*>(&ep[row * 40 + c4]);
+                const int co = cb * 32 + row, q = q0 + wt * 64 + half * 32 + c4;
+                const int t = q + a.out_off;
+                if (!live || co >= a.Cout || q >= a.Tq || t >= a.Tout) continue;
+                const size_t o = ob + (size_t)co * a.y_ld + t;
+                if (q + 3 < a.Tq && t + 3 < a.Tout) {
+                    const float bias = a.bias[co];
+                    f32x4 v = {v4[0] + bias, v4[1] + bias, v4[2] + bias, v4[3] + bias};
+                    if (a.res) { const f32x4 rr = *reinterpret_cast<const f32x4*>(a.res + o); v = v + rr; }
+                    if (a.res2) { const f32x4 rr = *reinterpret_cast<const f32x4*>(a.res2 + o); v = rr + v; }
+                    if (a.y) *reinterpret_cast<f32x4*>(a.y + o) = v;
+                    if (a.acc_mode == ACC_SET) *reinterpret_cast<f32x4*>(a.acc + o) = v;
+                    else if (a.acc_mode == ACC_ADD) { f32x4 p = *reinterpret_cast<f32x4*>(a.acc + o); *reinterpret_cast<f32x4*>(a.acc + o) = p + v; }
+                    else if (a.acc_mode == ACC_ADD_DIV3) {
+                        f32x4 p = *reinterpret_cast<f32x4*>(a.acc + o);
+                        p = p + v;
+                        *reinterpret_cast<f32x4*>(a.acc + o) = f32x4{p[0] / 3.0f, p[1] / 3.0f, p[2] / 3.0f, p[3] / 3.0f};
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (q + e < a.Tq && t + e < a.Tout) finish(v4[e], co, o + e);
+                }
+            }
+        }
+    } else if (live) {
+        // strided outputs (a transposed convolution's phases) or unaligned rows: one element at a time; a block of 32 rows
+        // never straddles two phases (phase_cout is a multiple of 32)
+        const int phase = a.phase_cout > 0 ? (cb * 32) / a.phase_cout : 0;
+        const int co_base = cb * 32 + 4 * (lane >> 5) - phase * a.phase_cout;
+        const int co_lim = a.Cout - phase * a.phase_cout;    // co_base + 8 (r / 4) + r % 4 must stay below
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int q = q0 + wt * 64 + half * 32 + (lane & 31);
+            const long long t = (long long)q * a.out_stride + a.out_off + phase;
+            if (q >= a.Tq || t < 0 || t >= a.Tout) continue;
+            const unsigned o0 = (unsigned)co_base * (unsigned)a.y_ld + (unsigned)t;   // inside the utterance: below 2^32
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int dco = 8 * (r >> 2) + (r & 3);
+                if (co_base + dco >= co_lim) continue;
+                finish(half ? acc1[r] : acc0[r], co_base + dco, ob + o0 + (unsigned)dco * (unsigned)a.y_ld);
+            }
         }
     }
     S3_STAMP();

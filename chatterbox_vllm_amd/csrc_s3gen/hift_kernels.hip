@@ -18,6 +18,7 @@
 //    residual blocks of a stage.  Outputs may be strided (out_stride, out_off): a transposed convolution runs as one
 //    plain convolution per output phase.
 #include "hift_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -59,9 +60,10 @@ __device__ __forceinline__ float apply_act(float v, float al, float inv, float s
     else return v;
 }
 
-template <int WCO, int WT, int ACT>
+// WCO x WT waves along channels x time; a wave owns 32 channels x (32 WN) positions as WN accumulators.
+template <int WCO, int WT, int WN, int ACT>
 __global__ __launch_bounds__(256) void conv1d_kernel(ConvArgs a) {
-    constexpr int MT = 32 * WCO, NT = 64 * WT, XW = NT + 96, NCOL = (NT + CONV_MAX_HALO + 63) / 64;
+    constexpr int MT = 32 * WCO, WV = 32 * WN, NT = WV * WT, XW = NT + 96, NCOL = (NT + CONV_MAX_HALO + 63) / 64;
     static_assert(WCO * WT == 4 && XW % 64 == 32 && NCOL * 64 <= XW, "tile shape");
     __shared__ float xs[2][CONV_CK][XW];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -108,9 +110,10 @@ __global__ __launch_bounds__(256) void conv1d_kernel(ConvArgs a) {
 #define S3_STAMP() do { } while (0)
 #endif
     S3_STAMP();
-    f32x16 acc0, acc1;
+    static_assert(WN == 2 || WN == 4, "two or four accumulators per wave");
+    f32x16 acc0, acc1, acc2, acc3;                            // acc2, acc3: WN == 4 only
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; acc2[i] = 0.f; acc3[i] = 0.f; }
     const int nchunk = a.Cin / CONV_CK, g8 = a.Cin / 8;
     const int cb = (co0 >> 5) + wco;                          // this wave's block of 32 output channels
     const bool live = cb * 32 < a.CoutPad;
@@ -127,7 +130,7 @@ __global__ __launch_bounds__(256) void conv1d_kernel(ConvArgs a) {
         if (more) load_chunk((ch + 1) * CONV_CK);
         S3_STAMP();
         if (live) {
-            const float* xrow = &xs[buf][lane >> 5][wt * 64 + (lane & 31)];
+            const float* xrow = &xs[buf][lane >> 5][wt * WV + (lane & 31)];
             for (int tap = 0; tap < a.K; ++tap) {
                 // the step after (ch, tap) is (ch, tap + 1), or (ch + 1, 0); the last step re-reads its own tile
                 const bool wrap = tap + 1 == a.K;
@@ -141,6 +144,11 @@ __global__ __launch_bounds__(256) void conv1d_kernel(ConvArgs a) {
                     const float b0 = xp[(2 * kk) * XW], b1 = xp[(2 * kk) * XW + 32];
                     acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc0, 0, 0, 0);
                     acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc1, 0, 0, 0);
+                    if constexpr (WN == 4) {
+                        const float b2 = xp[(2 * kk) * XW + 64], b3 = xp[(2 * kk) * XW + 96];
+                        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b2, acc2, 0, 0, 0);
+                        acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b3, acc3, 0, 0, 0);
+                    }
                 }
                 A0 = N0;
                 A1 = N1;
@@ -169,15 +177,16 @@ __global__ __launch_bounds__(256) void conv1d_kernel(ConvArgs a) {
         // buffer and comes back as four 16-byte pieces per lane, 8 rows x 128 bytes per store instruction
         float* ep = &xs[0][0][0] + w * (32 * 40);
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
+        for (int half = 0; half < WN; ++half) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                ep[(8 * (r >> 2) + 4 * (lane >> 5) + (r & 3)) * 40 + (lane & 31)] = half ? acc1[r] : acc0[r];
+                ep[(8 * (r >> 2) + 4 * (lane >> 5) + (r & 3)) * 40 + (lane & 31)] =
+                    half == 0 ? acc0[r] : (half == 1 ? acc1[r] : (half == 2 ? acc2[r] : acc3[r]));
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = i * 8 + (lane >> 3), c4 = (lane & 7) * 4;
                 const f32x4 v4 = *reinterpret_cast<const f32x4*>(&ep[row * 40 + c4]);
-                const int co = cb * 32 + row, q = q0 + wt * 64 + half * 32 + c4;
+                const int co = cb * 32 + row, q = q0 + wt * WV + half * 32 + c4;
                 const int t = q + a.out_off;
                 if (!live || co >= a.Cout || q >= a.Tq || t >= a.Tout) continue;
                 const size_t o = ob + (size_t)co * a.y_ld + t;
@@ -208,8 +217,8 @@ __global__ __launch_bounds__(256) void conv1d_kernel(ConvArgs a) {
         const int co_base = cb * 32 + 4 * (lane >> 5) - phase * a.phase_cout;
         const int co_lim = a.Cout - phase * a.phase_cout;    // co_base + 8 (r / 4) + r % 4 must stay below
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const int q = q0 + wt * 64 + half * 32 + (lane & 31);
+        for (int half = 0; half < WN; ++half) {
+            const int q = q0 + wt * WV + half * 32 + (lane & 31);
             const long long t = (long long)q * a.out_stride + a.out_off + phase;
             if (q >= a.Tq || t < 0 || t >= a.Tout) continue;
             const unsigned o0 = (unsigned)co_base * (unsigned)a.y_ld + (unsigned)t;   // inside the utterance: below 2^32
@@ -217,7 +226,7 @@ __global__ __launch_bounds__(256) void conv1d_kernel(ConvArgs a) {
             for (int r = 0; r < 16; ++r) {
                 const int dco = 8 * (r >> 2) + (r & 3);
                 if (co_base + dco >= co_lim) continue;
-                finish(half ? acc1[r] : acc0[r], co_base + dco, ob + o0 + (unsigned)dco * (unsigned)a.y_ld);
+                finish(half == 0 ? acc0[r] : (half == 1 ? acc1[r] : (half == 2 ? acc2[r] : acc3[r])), co_base + dco, ob + o0 + (unsigned)dco * (unsigned)a.y_ld);
             }
         }
     }
@@ -398,12 +407,20 @@ int launch_conv1d(const ConvArgs& a, int B, hipStream_t st) {
     S3_REQUIRE(a.Tq >= 1 && B >= 1, "conv1d: empty launch");
     S3_REQUIRE((long long)a.Cout * a.y_ld < (1LL << 32), "conv1d: utterance above 2^32 elements");
     S3_REQUIRE(a.phase_cout % 32 == 0, "conv1d: stacked phases must be whole blocks of 32 channels");
-    const bool wide = a.CoutPad >= 64;
-    const dim3 grid = wide ? dim3((a.Tq + 127) / 128, (a.CoutPad + 63) / 64, B) : dim3((a.Tq + 255) / 256, 1, B);
+    // tile shapes: 64 channels x 128 positions (5 workgroups per CU); 64 x 256 with four accumulators per wave (3 per CU,
+    // half the weight loads and barriers per matrix instruction: 3 % faster at 128 and 256 channels when the launch still
+    // has 1.5 tiles per CU, slower at 64 channels); 32 x 256 for the 18 output rows of conv_post
+    static const int force = getenv("S3HIFT_TILE") ? atoi(getenv("S3HIFT_TILE")) : -1;
+    const long long big_tiles = (long long)((a.Tq + 255) / 256) * ((a.CoutPad + 63) / 64) * B;
+    int shape = a.CoutPad < 64 ? 2 : ((a.CoutPad >= 128 && big_tiles >= 384) ? 1 : 0);
+    if (force >= 0 && a.CoutPad >= 64) shape = force;
+    const dim3 grid = shape == 0 ? dim3((a.Tq + 127) / 128, (a.CoutPad + 63) / 64, B)
+                    : shape == 1 ? dim3((a.Tq + 255) / 256, (a.CoutPad + 63) / 64, B) : dim3((a.Tq + 255) / 256, 1, B);
 #define S3_CONV_LAUNCH(ACT)                                                                                   \
     do {                                                                                                      \
-        if (wide) hipLaunchKernelGGL((conv1d_kernel<2, 2, ACT>), grid, dim3(256), 0, st, a);                  \
-        else hipLaunchKernelGGL((conv1d_kernel<1, 4, ACT>), grid, dim3(256), 0, st, a);                       \
+        if (shape == 0) hipLaunchKernelGGL((conv1d_kernel<2, 2, 2, ACT>), grid, dim3(256), 0, st, a);         \
+        else if (shape == 1) hipLaunchKernelGGL((conv1d_kernel<2, 2, 4, ACT>), grid, dim3(256), 0, st, a);    \
+        else hipLaunchKernelGGL((conv1d_kernel<1, 4, 2, ACT>), grid, dim3(256), 0, st, a);                    \
     } while (0)
     switch (a.act) {
         case ACT_NONE: S3_CONV_LAUNCH(ACT_NONE); break;

@@ -383,6 +383,9 @@ def main():
                     help="prompt positions (per stream) one prefill job may hold; vLLM's counterpart is max_num_batched_tokens")
     ap.add_argument("--no-prefix-sharing", action="store_true",
                     help="every stream prefills and keeps its own copy of the 34 conditioning positions (same ids)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group even with one rank (under torchrun --nproc-per-node 1): runs the "
+                         "RCCL broadcast / all-reduce / all-gather code path on a one-GPU box")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="collective backend under torchrun; gloo (CPU tensors, ranks may share a GPU) rehearses the "
                          "multi-rank path on a box with fewer GPUs than ranks")
@@ -403,8 +406,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.rehearse:
         args.backend = "gloo"
+    # stdout carries the one JSON line and nothing else: whatever libraries print there while the job runs (RCCL's
+    # version banner, for one) goes to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     dist = None
-    if world > 1:
+    if world > 1 or (args.force_dist and "RANK" in os.environ):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "gloo":
@@ -541,6 +549,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.rehearse:   # the CPU leg is timed on the one-GPU run only
         cb, cpu_ids, sub = cpu_baseline(cfg, sd, job, conds, paired=paired)
         result["cpu_baseline"] = cb
+    sys.stdout.flush()
+    os.dup2(json_fd, 1)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if dist is not None:

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void conv1d_kernel(ConvArgs a) {
 #define S3_STAMP() do { } while (0)
 #endif
     S3_STAMP();
-    static_assert(WN == 2 || WN == 4, "two or four accumulators per wave");
+    static_assert(WN == 1 || WN == 2 || WN == 4, "one, two or four accumulators per wave");
     f32x16 acc0, acc1, acc2, acc3;                            // acc2, acc3: WN == 4 only
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; acc2[i] = 0.f; acc3[i] = 0.f; }
@@ -141,9 +141,12 @@ __global__ __launch_bounds__(256) void conv1d_kernel(ConvArgs a) {
 #pragma unroll
                 for (int kk = 0; kk < 8; ++kk) {
                     const float av = kk < 4 ? A0[kk & 3] : A1[kk & 3];
-                    const float b0 = xp[(2 * kk) * XW], b1 = xp[(2 * kk) * XW + 32];
+                    const float b0 = xp[(2 * kk) * XW];
                     acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc1, 0, 0, 0);
+                    if constexpr (WN >= 2) {
+                        const float b1 = xp[(2 * kk) * XW + 32];
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc1, 0, 0, 0);
+                    }
                     if constexpr (WN == 4) {
                         const float b2 = xp[(2 * kk) * XW + 64], b3 = xp[(2 * kk) * XW + 96];
                         acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b2, acc2, 0, 0, 0);
@@ -413,13 +416,17 @@ int launch_conv1d(const ConvArgs& a, int B, hipStream_t st) {
     static const int force = getenv("S3HIFT_TILE") ? atoi(getenv("S3HIFT_TILE")) : -1;
     const long long big_tiles = (long long)((a.Tq + 255) / 256) * ((a.CoutPad + 63) / 64) * B;
     int shape = a.CoutPad < 64 ? 2 : ((a.CoutPad >= 128 && big_tiles >= 384) ? 1 : 0);
+    // short launches (one utterance): 64 x 64 tiles, so that the launch has more workgroups than the chip has CUs
+    if (shape == 0 && big_tiles * 2 < 384) shape = 3;
     if (force >= 0 && a.CoutPad >= 64) shape = force;
     const dim3 grid = shape == 0 ? dim3((a.Tq + 127) / 128, (a.CoutPad + 63) / 64, B)
-                    : shape == 1 ? dim3((a.Tq + 255) / 256, (a.CoutPad + 63) / 64, B) : dim3((a.Tq + 255) / 256, 1, B);
+                    : shape == 1 ? dim3((a.Tq + 255) / 256, (a.CoutPad + 63) / 64, B)
+                    : shape == 3 ? dim3((a.Tq + 63) / 64, (a.CoutPad + 63) / 64, B) : dim3((a.Tq + 255) / 256, 1, B);
 #define S3_CONV_LAUNCH(ACT)                                                                                   \
     do {                                                                                                      \
         if (shape == 0) hipLaunchKernelGGL((conv1d_kernel<2, 2, 2, ACT>), grid, dim3(256), 0, st, a);         \
         else if (shape == 1) hipLaunchKernelGGL((conv1d_kernel<2, 2, 4, ACT>), grid, dim3(256), 0, st, a);    \
+        else if (shape == 3) hipLaunchKernelGGL((conv1d_kernel<2, 2, 1, ACT>), grid, dim3(256), 0, st, a);    \
         else hipLaunchKernelGGL((conv1d_kernel<1, 4, 2, ACT>), grid, dim3(256), 0, st, a);                    \
     } while (0)
     switch (a.act) {

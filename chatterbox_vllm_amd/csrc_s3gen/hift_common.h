@@ -3,12 +3,13 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <string>
+#include <vector>
 #include "../../include/s3hift_hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-enum { ACT_NONE = 0, ACT_SNAKE = 1, ACT_LRELU = 2, ACT_ELU = 3 };
+enum { ACT_NONE = 0, ACT_SNAKE = 1, ACT_LRELU = 2, ACT_ELU = 3, ACT_SWISH = 4 };
 enum { ACC_NONE = 0, ACC_SET = 1, ACC_ADD = 2, ACC_ADD_DIV3 = 3 };
 
 #define CONV_CK 16          // input channels per LDS tile
@@ -45,6 +46,22 @@ int launch_f0_head(const float* x, int ld, size_t x_bs, int C, int T, const floa
 int launch_source(const float* f0, int T, double* prefix, const float* phase, const float* noise, uint64_t seed, const float* lw,
                   const float* lb, float* s, int B, hipStream_t st);
 int launch_overwrite_head(float* s, int L, const float* cache, int n_cache, int B, hipStream_t st);
+
+// W[Cout][Cin][K] (row-major) -> the convolution kernel's tile order (ConvArgs::wt), output channels padded to 32
+inline std::vector<float> s3_tile_conv_weights(const float* w, int Cout, int Cin, int K) {
+    const int g8 = Cin / 8, nb = (Cout + 31) / 32;
+    std::vector<float> t((size_t)nb * K * g8 * 256, 0.f);
+    for (int cb = 0; cb < nb; ++cb)
+        for (int tap = 0; tap < K; ++tap)
+            for (int g = 0; g < g8; ++g)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 4; ++j) {
+                        const int co = cb * 32 + (lane & 31), ci = g * 8 + 2 * j + (lane >> 5);
+                        if (co < Cout)
+                            t[((((size_t)cb * K + tap) * g8 + g) * 64 + lane) * 4 + j] = w[((size_t)co * Cin + ci) * K + tap];
+                    }
+    return t;
+}
 
 void s3_set_error(const std::string& msg);
 #define S3_HIP_CHECK(expr)                                                                   \

@@ -75,17 +75,7 @@ int upload(s3hift* h, float** dst, const float* src, size_t n) {
 int make_conv_from(s3hift* h, Conv* c, const float* w, const float* bias, int Cout, int Cin, int K, int n_bias = 0) {
     S3_REQUIRE(Cin % CONV_CK == 0, "convolution input channels must be a multiple of 16");
     c->Cin = Cin; c->Cout = Cout; c->K = K; c->CoutPad = (Cout + 31) / 32 * 32;
-    const int g8 = Cin / 8, nb = c->CoutPad / 32;
-    std::vector<float> t((size_t)nb * K * g8 * 256, 0.f);
-    for (int cb = 0; cb < nb; ++cb)
-        for (int tap = 0; tap < K; ++tap)
-            for (int g = 0; g < g8; ++g)
-                for (int lane = 0; lane < 64; ++lane)
-                    for (int j = 0; j < 4; ++j) {
-                        const int co = cb * 32 + (lane & 31), ci = g * 8 + 2 * j + (lane >> 5);
-                        if (co < Cout)
-                            t[((((size_t)cb * K + tap) * g8 + g) * 64 + lane) * 4 + j] = w[((size_t)co * Cin + ci) * K + tap];
-                    }
+    const std::vector<float> t = s3_tile_conv_weights(w, Cout, Cin, K);
     if (upload(h, &c->wt, t.data(), t.size())) return 1;
     return upload(h, &c->bias, bias, n_bias ? n_bias : Cout);
 }

@@ -57,6 +57,7 @@ __device__ __forceinline__ float apply_act(float v, float al, float inv, float s
     if constexpr (ACT == ACT_SNAKE) return fmaf(inv, sin_sq(v * al), v);
     else if constexpr (ACT == ACT_LRELU) return v > 0.f ? v : v * slope;
     else if constexpr (ACT == ACT_ELU) return v > 0.f ? v : expf(v) - 1.0f;
+    else if constexpr (ACT == ACT_SWISH) return v * (1.0f / (1.0f + expf(-v)));
     else return v;
 }
 
@@ -434,6 +435,7 @@ int launch_conv1d(const ConvArgs& a, int B, hipStream_t st) {
         case ACT_SNAKE: S3_CONV_LAUNCH(ACT_SNAKE); break;
         case ACT_LRELU: S3_CONV_LAUNCH(ACT_LRELU); break;
         case ACT_ELU: S3_CONV_LAUNCH(ACT_ELU); break;
+        case ACT_SWISH: S3_CONV_LAUNCH(ACT_SWISH); break;
         default: S3_REQUIRE(false, "conv1d: unknown activation");
     }
 #undef S3_CONV_LAUNCH

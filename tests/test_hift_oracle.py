@@ -107,13 +107,15 @@ def test_inference_matches_the_reference(fx, w):
 
 
 def test_library_loads_and_exports_every_declared_symbol():
-    """libs3hift.so exports every function include/s3hift_hip.h declares, and the binding declares the same set."""
+    """libs3hift.so exports every function include/s3hift_hip.h and include/s3flow_hip.h declare, and the bindings declare
+    the same sets."""
     import re
-    from chatterbox_vllm_amd import hift
-    header = open(os.path.join(ROOT, "include", "s3hift_hip.h")).read()
-    declared = set(re.findall(r"\b(s3hift_[a-z0-9_]+)\s*\(", header))
-    assert declared == set(hift._SIGNATURES), declared ^ set(hift._SIGNATURES)
+    from chatterbox_vllm_amd import flow_encoder, hift
     lib = C.CDLL(hift.lib_path())
-    for name in declared:
-        assert hasattr(lib, name), name
+    for header, prefix, sigs in (("s3hift_hip.h", "s3hift_", hift._SIGNATURES), ("s3flow_hip.h", "s3flow_", flow_encoder._SIGNATURES)):
+        text = open(os.path.join(ROOT, "include", header)).read()
+        declared = set(re.findall(r"\b(" + prefix + r"[a-z0-9_]+)\s*\(", text))
+        assert declared == set(sigs), declared ^ set(sigs)
+        for name in declared:
+            assert hasattr(lib, name), name
     assert lib.s3hift_abi_version() == hift.ABI_VERSION

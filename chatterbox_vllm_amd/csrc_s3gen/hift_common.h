@@ -36,6 +36,20 @@ struct ConvArgs {
 };
 
 int launch_conv1d(const ConvArgs& a, int B, hipStream_t st);
+
+// One step of a residual block on 64-channel tensors in one launch (hifigan.py:156-160):
+//     y = conv2(snake(conv1(snake(x, alpha1), dilation), alpha2)) + x (+ res2), folded into `acc` per acc_mode.
+// The intermediate tensor never leaves the chip.  All tensors [batch][64][L] with row stride ld and batch stride bs.
+struct ResStepArgs {
+    const float* x;
+    const float *w1, *b1, *alpha1;      // conv1: tile order (ConvArgs::wt), bias, Snake alpha of its input; dilation `dil`
+    const float *w2, *b2, *alpha2;      // conv2: the same, dilation 1
+    float* y;                           // may be null (accumulate only)
+    const float* res2;                  // may be null
+    float* acc; int acc_mode;
+    size_t bs; int ld; int L; int K; int dil;
+};
+int launch_resblock_step64(const ResStepArgs& a, int B, hipStream_t st);
 int launch_stft(const float* s, int L, float* out, int M, int ld, size_t out_bs, int B, hipStream_t st);
 int launch_space_to_depth(const float* x, int x_ld, size_t x_bs, int Tin, int Cin, float* y, int y_ld, size_t y_bs, int Tq,
                           int Cpad, int stride, int pad, int B, hipStream_t st);

@@ -125,12 +125,30 @@ int run_resblock(s3hift* h, Stage& s, const ResBlock& rb, const float* in, float
                  int B, hipStream_t st) {
     const size_t bs = (size_t)s.C * s.ld;
     const float* cur = in;
+    // 64-channel tensors can take both convolutions of a step in one launch, the tensor between them kept on the chip (same
+    // bits).  Built to cut three of five tensor passes over HBM; measured slower (stage 2 of 8 x 500 frames: 8.05 against
+    // 7.23 ms: 3 workgroups per CU instead of 5, 7 % more matrix work, a Snake pass nothing overlaps), so off unless
+    // S3HIFT_FUSED=1.
+    const char* fused_env = getenv("S3HIFT_FUSED");
+    const bool fused = fused_env && atoi(fused_env) == 1 && s.C == 64;
     for (int i = 0; i < 3; ++i) {
+        const bool last = i == 2;
+        float* out = last ? final_y : (i == 0 ? s.U0 : s.U1);
+        if (fused) {
+            ResStepArgs r{};
+            r.x = cur;
+            r.w1 = rb.c1[i].wt; r.b1 = rb.c1[i].bias; r.alpha1 = rb.a1[i];
+            r.w2 = rb.c2[i].wt; r.b2 = rb.c2[i].bias; r.alpha2 = rb.a2[i];
+            r.y = out;
+            if (last) { r.res2 = res2; r.acc = s.XS; r.acc_mode = acc_mode; }
+            r.bs = bs; r.ld = s.ld; r.L = s.L; r.K = rb.k; r.dil = kDil[i];
+            if (launch_resblock_step64(r, B, st)) return 1;
+            cur = out;
+            continue;
+        }
         ConvArgs a = conv_args(rb.c1[i], cur, bs, s.ld, s.L, s.T1, bs, s.ld, s.L);
         a.act = ACT_SNAKE; a.alpha = rb.a1[i]; a.dil = kDil[i]; a.pad = (rb.k * kDil[i] - kDil[i]) / 2;
         if (launch_conv1d(a, B, st)) return 1;
-        const bool last = i == 2;
-        float* out = last ? final_y : (i == 0 ? s.U0 : s.U1);
         ConvArgs c = conv_args(rb.c2[i], s.T1, bs, s.ld, s.L, out, bs, s.ld, s.L);
         c.act = ACT_SNAKE; c.alpha = rb.a2[i]; c.pad = (rb.k - 1) / 2;
         c.res = cur;

@@ -403,6 +403,173 @@ __global__ void overwrite_head_kernel(float* __restrict__ s, int L, const float*
     if (i < n_cache && i < L) s[(size_t)b * L + i] = cache[(size_t)b * n_cache + i];
 }
 
+// One residual-block step for 64 channels: both convolutions of the step in one workgroup, the tensor between them kept in
+// LDS.  A workgroup produces NTO = 128 - 2 ((K - 1) / 2 rounded up to a multiple of 2) consecutive outputs (a multiple of
+// 4, so rows stay 16-byte aligned): conv1 is evaluated on the 128 positions that conv2's taps reach (its own taps reach
+// another (K - 1) dil / 2 to each side in the input tile), Snake(alpha2) of it goes to LDS as [64][128 (+ taps)], zero
+// where the position lies outside the tensor (conv2's zero padding), and conv2 reads it at shifted columns.  Both
+// convolutions sum in the order of conv1d_kernel (16 channels at a time, taps, pairs of channels), so the result has the
+// bits of the two-launch form; it costs 128 / NTO = 3-10 % more matrix work and saves three of five tensor passes over
+// HBM and one launch.
+__global__ __launch_bounds__(256) void resblock_step64_kernel(ResStepArgs a, int nto, int p2) {
+    constexpr int NT = 128, XW = NT + 96, NCOL = 3, TW = 160;      // TW: row stride of the intermediate tile (32 mod 64)
+    __shared__ float lds[64 * TW];                                 // 40 KiB: the input tile buffers, then the intermediate tile
+    float (*xs)[CONV_CK][XW] = reinterpret_cast<float (*)[CONV_CK][XW]>(lds);   // [2][16][224] = 28 KiB of it
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wco = w & 1, wt = w >> 1;
+    const int q0 = blockIdx.x * nto, b = blockIdx.y;
+    const float* __restrict__ xb = a.x + (size_t)b * a.bs;
+    const int p1 = (a.K - 1) * a.dil / 2;
+    const int span = NT + (a.K - 1) * a.dil;
+    const int tin0 = q0 - p2 - p1;                                 // input position of tile column 0
+    int tcl[NCOL];
+    bool ok[NCOL];
+#pragma unroll
+    for (int j = 0; j < NCOL; ++j) {
+        const int c = lane + 64 * j, t = tin0 + c;
+        ok[j] = c < span && t >= 0 && t < a.L;
+        tcl[j] = t < 0 ? 0 : (t >= a.L ? a.L - 1 : t);
+    }
+    float raw[4][NCOL];
+    auto load_chunk = [&](int ci0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float* xr = xb + (size_t)(ci0 + w * 4 + r) * a.ld;
+#pragma unroll
+            for (int j = 0; j < NCOL; ++j) raw[r][j] = xr[tcl[j]];
+        }
+    };
+    auto store_chunk = [&](int buf, int ci0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float al = a.alpha1[ci0 + w * 4 + r], inv = 1.0f / (al + 1e-9f);
+#pragma unroll
+            for (int j = 0; j < NCOL; ++j)
+                xs[buf][w * 4 + r][lane + 64 * j] = ok[j] ? apply_act<ACT_SNAKE>(raw[r][j], al, inv, 0.f) : 0.f;
+        }
+    };
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+    constexpr int g8 = 8, nchunk = 4;                              // 64 input channels
+    const f32x4* __restrict__ w1 = reinterpret_cast<const f32x4*>(a.w1) + (size_t)wco * a.K * g8 * 64 + lane;
+    const f32x4* __restrict__ w2 = reinterpret_cast<const f32x4*>(a.w2) + (size_t)wco * a.K * g8 * 64 + lane;
+
+    // ---- conv1 (dilated) over the 128 positions q0 - p2 .. q0 - p2 + 127
+    load_chunk(0);
+    f32x4 A0 = w1[0], A1 = w1[64];
+    store_chunk(0, 0);
+    __syncthreads();
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const int buf = ch & 1;
+        const bool more = ch + 1 < nchunk;
+        if (more) load_chunk((ch + 1) * CONV_CK);
+        const float* xrow = &xs[buf][lane >> 5][wt * 64 + (lane & 31)];
+        for (int tap = 0; tap < a.K; ++tap) {
+            const bool wrap = tap + 1 == a.K;
+            // after the last step of conv1 come the first weights of conv2
+            const f32x4* np = wrap ? (more ? w1 + (size_t)((ch + 1) * 2) * 64 : w2) : w1 + ((size_t)(tap + 1) * g8 + ch * 2) * 64;
+            const f32x4 N0 = np[0], N1 = np[64];
+            const float* xp = xrow + tap * a.dil;
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const float av = kk < 4 ? A0[kk & 3] : A1[kk & 3];
+                const float b0 = xp[(2 * kk) * XW], b1 = xp[(2 * kk) * XW + 32];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc1, 0, 0, 0);
+            }
+            A0 = N0;
+            A1 = N1;
+        }
+        if (more) store_chunk(buf ^ 1, (ch + 1) * CONV_CK);
+        __syncthreads();
+    }
+    // ---- Snake(alpha2) of (conv1 + bias1) -> the intermediate tile; zero outside the tensor and in the tap margin
+    float (*xt)[TW] = reinterpret_cast<float (*)[TW]>(lds);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int c = wt * 64 + half * 32 + (lane & 31);
+        const int pos = q0 - p2 + c;
+        const bool inside = pos >= 0 && pos < a.L;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = wco * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+            const float al = a.alpha2[co], inv = 1.0f / (al + 1e-9f);
+            const float v = (half ? acc1[r] : acc0[r]) + a.b1[co];
+            xt[co][c] = inside ? apply_act<ACT_SNAKE>(v, al, inv, 0.f) : 0.f;
+        }
+    }
+    if (tid < 64)
+#pragma unroll
+        for (int c = NT; c < TW; ++c) xt[tid][c] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+    __syncthreads();
+    // ---- conv2 (dilation 1): output column j is position q0 + j and reads intermediate columns j .. j + K - 1
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const float* xrow = &xt[ch * CONV_CK + (lane >> 5)][wt * 64 + (lane & 31)];
+        for (int tap = 0; tap < a.K; ++tap) {
+            const bool wrap = tap + 1 == a.K, more = ch + 1 < nchunk;
+            const f32x4* np = wrap ? (more ? w2 + (size_t)((ch + 1) * 2) * 64 : w2 + ((size_t)tap * g8 + ch * 2) * 64)
+                                   : w2 + ((size_t)(tap + 1) * g8 + ch * 2) * 64;
+            const f32x4 N0 = np[0], N1 = np[64];
+            const float* xp = xrow + tap;
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const float av = kk < 4 ? A0[kk & 3] : A1[kk & 3];
+                const float b0 = xp[(2 * kk) * TW], b1 = xp[(2 * kk) * TW + 32];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc1, 0, 0, 0);
+            }
+            A0 = N0;
+            A1 = N1;
+        }
+    }
+    __syncthreads();                                               // the intermediate tile is free: reuse it for the transpose
+    // ---- epilogue as in conv1d_kernel: 32 x 32 accumulators through LDS, 16-byte pieces per lane
+    const size_t ob = (size_t)b * a.bs;
+    float* ep = lds + w * (32 * 40);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            ep[(8 * (r >> 2) + 4 * (lane >> 5) + (r & 3)) * 40 + (lane & 31)] = half ? acc1[r] : acc0[r];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = i * 8 + (lane >> 3), c4 = (lane & 7) * 4;
+            const f32x4 v4 = *reinterpret_cast<const f32x4*>(&ep[row * 40 + c4]);
+            const int co = wco * 32 + row, j = wt * 64 + half * 32 + c4, q = q0 + j;
+            if (j >= nto || q >= a.L) continue;                    // nto and q0 are multiples of 4: pieces are whole or empty ...
+            const size_t o = ob + (size_t)co * a.ld + q;
+            const float bias = a.b2[co];
+            if (q + 3 < a.L) {
+                f32x4 v = {v4[0] + bias, v4[1] + bias, v4[2] + bias, v4[3] + bias};
+                v = v + *reinterpret_cast<const f32x4*>(a.x + o);
+                if (a.res2) { const f32x4 rr = *reinterpret_cast<const f32x4*>(a.res2 + o); v = rr + v; }
+                if (a.y) *reinterpret_cast<f32x4*>(a.y + o) = v;
+                if (a.acc_mode == ACC_SET) *reinterpret_cast<f32x4*>(a.acc + o) = v;
+                else if (a.acc_mode == ACC_ADD) { f32x4 p = *reinterpret_cast<f32x4*>(a.acc + o); *reinterpret_cast<f32x4*>(a.acc + o) = p + v; }
+                else if (a.acc_mode == ACC_ADD_DIV3) {
+                    f32x4 p = *reinterpret_cast<f32x4*>(a.acc + o);
+                    p = p + v;
+                    *reinterpret_cast<f32x4*>(a.acc + o) = f32x4{p[0] / 3.0f, p[1] / 3.0f, p[2] / 3.0f, p[3] / 3.0f};
+                }
+            } else {                                               // ... except at the tensor's end
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (q + e >= a.L) continue;
+                    float v = v4[e] + bias;
+                    v = v + a.x[o + e];
+                    if (a.res2) v = a.res2[o + e] + v;
+                    if (a.y) a.y[o + e] = v;
+                    if (a.acc_mode == ACC_SET) a.acc[o + e] = v;
+                    else if (a.acc_mode == ACC_ADD) a.acc[o + e] = a.acc[o + e] + v;
+                    else if (a.acc_mode == ACC_ADD_DIV3) a.acc[o + e] = (a.acc[o + e] + v) / 3.0f;
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 int launch_conv1d(const ConvArgs& a, int B, hipStream_t st) {
@@ -488,6 +655,17 @@ int launch_source(const float* f0, int T, double* prefix, const float* phase, co
 int launch_overwrite_head(float* s, int L, const float* cache, int n_cache, int B, hipStream_t st) {
     if (n_cache <= 0) return 0;
     hipLaunchKernelGGL(overwrite_head_kernel, dim3((n_cache + 255) / 256, B), dim3(256), 0, st, s, L, cache, n_cache);
+    S3_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_resblock_step64(const ResStepArgs& a, int B, hipStream_t st) {
+    S3_REQUIRE(a.K >= 1 && (a.K & 1) && (a.K - 1) * a.dil <= CONV_MAX_HALO && a.K - 1 <= 32, "resblock step: kernel span");
+    S3_REQUIRE(a.ld % 4 == 0 && a.bs % 4 == 0 && a.L >= 1 && B >= 1, "resblock step: rows must be 16-byte aligned");
+    S3_REQUIRE((long long)64 * a.ld < (1LL << 32), "resblock step: utterance above 2^32 elements");
+    const int p2 = (a.K - 1) / 2;
+    const int nto = (128 - 2 * p2) & ~3;                           // outputs per workgroup, a multiple of 4
+    hipLaunchKernelGGL(resblock_step64_kernel, dim3((a.L + nto - 1) / nto, B), dim3(256), 0, st, a, nto, p2);
     S3_HIP_CHECK(hipGetLastError());
     return 0;
 }

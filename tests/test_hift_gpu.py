@@ -203,6 +203,19 @@ def test_interior_of_a_long_utterance_equals_the_interior_of_a_window(gen):
     assert torch.equal(whole[0, a * 480: b * 480], part[0, (a - lo) * 480: (b - lo) * 480])
 
 
+def test_fused_residual_step_gives_the_same_bits(gen, monkeypatch):
+    """The one-launch form of a residual-block step on the 64-channel stage (off by default: measured slower) must give
+    the two-launch form's waveform bit for bit."""
+    T = 40
+    mel = HW.synthetic_mel(T, seed=51, batch=2)
+    s = handmade_source(T, 2, 52)
+    base = gen.decode(mel, s).clone()
+    monkeypatch.setenv("S3HIFT_FUSED", "1")
+    fused = gen.decode(mel, s).clone()
+    monkeypatch.delenv("S3HIFT_FUSED")
+    assert torch.equal(fused, base)
+
+
 def test_workspace_limits_are_errors(gen):
     with pytest.raises(ValueError):
         gen.decode(HW.synthetic_mel(321, seed=1), torch.zeros(1, 1, 321 * 480))

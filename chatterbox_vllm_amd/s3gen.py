@@ -1,0 +1,67 @@
+"""Token -> waveform with the stages this package has on the GPU, around a flow-matching decoder supplied by the caller.
+
+Mirror of the reference's ``S3Token2Wav.inference`` (src/chatterbox_vllm/models/s3gen/s3gen.py:297-317) for a pre-computed
+reference dict (``ref_dict``, the "prod API" of s3gen.py:176-186, as ``ChatterboxTTS`` passes it, tts.py:489-493):
+
+    speech tokens --FlowEncoder--> mu, spks, cond --decoder (caller's)--> mel --HiFTGenerator--> waveform --trim fade-->
+
+``decoder`` is any callable with the reference decoder's call signature (flow.py:268-274):
+``decoder(mu=[1, 80, L], mask=[1, 1, L], spks=[1, 80], cond=[1, 80, L], n_timesteps=int) -> (mel [1, 80, L], _)``.
+With the reference installed that is ``s3gen.flow.decoder``; this package does not contain one (the reference's needs
+libraries that are absent here, so it could not be checked)."""
+from __future__ import annotations
+
+from typing import Callable, Dict, Optional, Tuple
+
+import torch
+
+from .flow_encoder import FlowEncoder
+from .hift import HiFTGenerator
+
+S3GEN_SR = 24000
+
+
+class S3Token2Wav:
+    def __init__(self, flow_state_dict: Dict[str, torch.Tensor], mel2wav_state_dict: Dict[str, torch.Tensor],
+                 decoder: Callable, max_tokens: int = 1500, device: int = 0):
+        self.device = torch.device("cuda", device)
+        self.encoder = FlowEncoder(flow_state_dict, max_tokens=max_tokens, device=device)
+        self.mel2wav = HiFTGenerator(mel2wav_state_dict, max_batch=1, max_frames=2 * max_tokens, device=device)
+        self.decoder = decoder
+        # silence the first 20 ms and fade in over the next 20 ms (s3gen.py:247-251)
+        n_trim = S3GEN_SR // 50
+        fade = torch.zeros(2 * n_trim)
+        fade[n_trim:] = (torch.cos(torch.linspace(torch.pi, 0, n_trim)) + 1) / 2
+        self.trim_fade = fade.to(self.device)
+
+    @torch.inference_mode()
+    def flow_inference(self, speech_tokens: torch.Tensor, ref_dict: dict, n_timesteps: int = 10) -> torch.Tensor:
+        """s3gen.py:277-288 with finalize=True: mel [1, 80, 2 T_new]."""
+        if speech_tokens.dim() == 1:
+            speech_tokens = speech_tokens.unsqueeze(0)
+        d = self.encoder.decoder_inputs(speech_tokens, ref_dict["prompt_token"], ref_dict["prompt_feat"], ref_dict["embedding"])
+        mel_len1 = d.pop("prompt_len")
+        feat, _ = self.decoder(mu=d["mu"], mask=d["mask"], spks=d["spks"], cond=d["cond"], n_timesteps=n_timesteps)
+        feat = feat[:, :, mel_len1:]
+        assert feat.shape[2] == 2 * speech_tokens.shape[1], "the decoder must return one mel frame per mu column"
+        return feat.float()
+
+    @torch.inference_mode()
+    def hift_inference(self, speech_feat: torch.Tensor, cache_source: Optional[torch.Tensor] = None, seed: int = 0):
+        """s3gen.py:290-294."""
+        return self.mel2wav.inference(speech_feat, cache_source, seed=seed)
+
+    @torch.inference_mode()
+    def inference(self, speech_tokens: torch.Tensor, ref_dict: dict, cache_source: Optional[torch.Tensor] = None,
+                  no_trim: bool = False, n_timesteps: int = 10, seed: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
+        """s3gen.py:296-317: (waveform [1, 480 * 2 T_new], source)."""
+        mels = self.flow_inference(speech_tokens, ref_dict, n_timesteps)
+        wav, src = self.hift_inference(mels, cache_source, seed=seed)
+        if not no_trim:
+            n = min(wav.shape[1], self.trim_fade.numel())
+            wav[:, :n] *= self.trim_fade[:n]
+        return wav, src
+
+    def shutdown(self) -> None:
+        self.encoder.shutdown()
+        self.mel2wav.shutdown()

@@ -72,3 +72,33 @@ def test_longer_utterance_against_the_fp64_oracle(enc):
 def test_workspace_limit_is_an_error(enc):
     with pytest.raises(ValueError):
         enc.token_to_mu(FW.synthetic_tokens(261))
+
+
+def test_token_to_waveform_chain_around_a_callers_decoder(fx):
+    """S3Token2Wav: encoder -> (caller's decoder) -> vocoder -> trim fade, with a stand-in decoder that returns a fixed
+    function of its inputs: the decoder sees the reference's tensors, the waveform is the vocoder's for the returned mel
+    with the first 20 ms silenced and the next 20 ms faded in (s3gen.py:247-251, 313-315)."""
+    from chatterbox_vllm_amd import hift_weights as HW
+    from chatterbox_vllm_amd.s3gen import S3Token2Wav
+    seen = {}
+
+    def decoder(mu, mask, spks, cond, n_timesteps):
+        seen.update(mu=mu.clone(), spks=spks.clone(), cond=cond.clone(), n=n_timesteps)
+        return -4.0 + 0.5 * torch.tanh(mu) + 0.0 * cond, None
+
+    s3 = S3Token2Wav(FW.synthetic_state_dict(), HW.synthetic_state_dict(), decoder, max_tokens=64)
+    n_prompt, n_new = int(fx["a_n_prompt"]), int(fx["a_n_new"])
+    ref = {"prompt_token": FW.synthetic_tokens(n_prompt, seed=3).view(1, -1), "prompt_feat": torch.from_numpy(fx["a_prompt_feat"]),
+           "embedding": torch.from_numpy(fx["a_xvec"])}
+    new = FW.synthetic_tokens(n_new, seed=4)
+    wav, src = s3.inference(new, ref, seed=3)
+    assert (seen["mu"].cpu() - torch.from_numpy(fx["a_mu"])).abs().max().item() <= 2e-5 and seen["n"] == 10
+    assert torch.equal(seen["cond"].cpu(), torch.from_numpy(fx["a_cond"]))
+    assert wav.shape == (1, 2 * n_new * 480) and src.shape == (1, 1, 2 * n_new * 480)
+    mel = (-4.0 + 0.5 * torch.tanh(seen["mu"]))[:, :, 2 * n_prompt:]
+    raw, _ = s3.hift_inference(mel, seed=3)
+    assert not wav[0, :480].any()
+    assert torch.equal(wav[0, 960:], raw[0, 960:])
+    fade = (torch.cos(torch.linspace(torch.pi, 0, 480)) + 1) / 2
+    assert torch.allclose(wav[0, 480:960].cpu(), raw[0, 480:960].cpu() * fade, atol=1e-7)
+    s3.shutdown()

@@ -377,7 +377,11 @@ __global__ __launch_bounds__(256) void source_kernel(const float* __restrict__ f
     for (int h = 0; h < S3HIFT_HARMONICS; ++h) {
         const float inc = f * (float)(h + 1) / 24000.0f;
         const double cum = prefix[((size_t)b * S3HIFT_HARMONICS + h) * T + m] + (double)(j + 1) * (double)inc;
-        const float frac = (float)(cum - floor(cum));
+        // the reference takes the running sum to fp32 before it takes the fractional part (torch.cumsum on the CPU sums in
+        // double and stores fp32; `% 1` then works on that fp32 value), which quantises the phase of long utterances to the
+        // fp32 spacing of the sum; the same here, so that the source is the reference's at every length
+        const float cs = (float)cum;
+        const float frac = cs - floorf(cs);
         const float theta = 6.283185307179586f * frac;
         float ph = 0.f;
         if (h > 0) {

@@ -34,37 +34,44 @@ __global__ void embed_gather_kernel(const int32_t* __restrict__ tok, int T, cons
     x[(size_t)c * ld + t] = emb[(size_t)id * kD + c];
 }
 
-// LayerNorm over the 512 channels of every position of a [512][T] tensor: 32 positions x 8 channel groups per workgroup,
-// mean, then the centred sum of squares, then y = ((x - mean) * rstd * gamma + beta) * scale.  In place is allowed.
+// LayerNorm over the 512 channels of every position of a [512][T] tensor: 8 positions x 32 channel groups per workgroup
+// (16 channels per thread, so a few hundred positions already make a hundred workgroups), mean, then the centred sum of
+// squares, then y = ((x - mean) * rstd * gamma + beta) * scale.  In place is allowed.
 __global__ __launch_bounds__(256) void layer_norm_kernel(const float* x, int ldx, float* y, int ldy, int T,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                          float scale) {
-    __shared__ float red[8][33];
-    const int tx = threadIdx.x & 31, cy = threadIdx.x >> 5;
-    const int t = blockIdx.x * 32 + tx;
+    __shared__ float red[32][9];
+    const int tx = threadIdx.x & 7, cy = threadIdx.x >> 3;
+    const int t = blockIdx.x * 8 + tx;
     const bool ok = t < T;
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = ok ? x[(size_t)(cy + 32 * i) * ldx + t] : 0.f;
     float s = 0.f;
-    if (ok)
-        for (int c = cy; c < kD; c += 8) s += x[(size_t)c * ldx + t];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += v[i];
     red[cy][tx] = s;
     __syncthreads();
     float mean = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) mean += red[i][tx];
+    for (int i = 0; i < 32; ++i) mean += red[i][tx];
     mean *= 1.0f / kD;
     __syncthreads();
-    float v = 0.f;
-    if (ok)
-        for (int c = cy; c < kD; c += 8) { const float d = x[(size_t)c * ldx + t] - mean; v = fmaf(d, d, v); }
-    red[cy][tx] = v;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { const float d = v[i] - mean; q = fmaf(d, d, q); }
+    red[cy][tx] = q;
     __syncthreads();
     float var = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) var += red[i][tx];
+    for (int i = 0; i < 32; ++i) var += red[i][tx];
     const float rstd = 1.0f / sqrtf(var * (1.0f / kD) + eps);
     if (ok)
-        for (int c = cy; c < kD; c += 8)
-            y[(size_t)c * ldy + t] = ((x[(size_t)c * ldx + t] - mean) * rstd * gamma[c] + beta[c]) * scale;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int c = cy + 32 * i;
+            y[(size_t)c * ldy + t] = ((v[i] - mean) * rstd * gamma[c] + beta[c]) * scale;
+        }
 }
 
 // EspnetRelPositionalEncoding (transformer/embedding.py:236-253, 290-293) for T positions, channel-major: column m holds
@@ -203,7 +210,8 @@ __global__ __launch_bounds__(256) void speaker_kernel(const float* __restrict__ 
 struct Host { std::vector<float> v; std::vector<int64_t> shape; };
 struct Lin { float* wt = nullptr; float* bias = nullptr; int Cin = 0, Cout = 0, K = 1; };   // a convolution for launch_conv1d
 struct Block {
-    Lin qu, qv, k, v, pos, out, w1, w2;        // qu / qv: linear_q with pos_bias_u / pos_bias_v added to its bias
+    Lin qkv;                                   // one projection with 2048 outputs: q + pos_bias_u, q + pos_bias_v, k, v
+    Lin pos, out, w1, w2;
     float *g_mha = nullptr, *b_mha = nullptr, *g_ff = nullptr, *b_ff = nullptr;
 };
 
@@ -285,7 +293,7 @@ int run_lin(const Lin& l, const float* x, int x_ld, int Tin, float* y, int y_ld,
 }
 
 int run_ln(const float* x, int ldx, float* y, int ldy, int T, const float* g, const float* b, float eps, float scale, hipStream_t st) {
-    hipLaunchKernelGGL(layer_norm_kernel, dim3((T + 31) / 32), dim3(256), 0, st, x, ldx, y, ldy, T, g, b, eps, scale);
+    hipLaunchKernelGGL(layer_norm_kernel, dim3((T + 7) / 8), dim3(256), 0, st, x, ldx, y, ldy, T, g, b, eps, scale);
     S3_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -300,10 +308,7 @@ int run_bgemm(const BGemm& g, int batch, hipStream_t st) {
 int run_block(s3flow_enc* h, const Block& b, int T, hipStream_t st) {
     const int ld = h->ld, ldp = h->ldp, P2 = 2 * T - 1;
     if (run_ln(h->X, ld, h->N, ld, T, b.g_mha, b.b_mha, 1e-12f, 1.0f, st)) return 1;
-    if (run_lin(b.qu, h->N, ld, T, h->QU, ld, T, 0, ACT_NONE, 0.f, nullptr, st)) return 1;
-    if (run_lin(b.qv, h->N, ld, T, h->QV, ld, T, 0, ACT_NONE, 0.f, nullptr, st)) return 1;
-    if (run_lin(b.k, h->N, ld, T, h->Kb, ld, T, 0, ACT_NONE, 0.f, nullptr, st)) return 1;
-    if (run_lin(b.v, h->N, ld, T, h->Vb, ld, T, 0, ACT_NONE, 0.f, nullptr, st)) return 1;
+    if (run_lin(b.qkv, h->N, ld, T, h->QU, ld, T, 0, ACT_NONE, 0.f, nullptr, st)) return 1;   // QU, QV, Kb, Vb are one buffer
     if (run_lin(b.pos, h->PE, ldp, P2, h->P, ldp, P2, 0, ACT_NONE, 0.f, nullptr, st)) return 1;
     const long long head = (long long)kDk * ld, headp = (long long)kDk * ldp;
     BGemm ac{h->QU, head, 1, ld, h->Kb, head, ld, 1, h->Sac, (long long)T * T, T, T, T, kDk};
@@ -381,10 +386,24 @@ extern "C" int s3flow_enc_finalize(s3flow_enc* h) {
         Block& b = h->blocks[i];
         const Host *u, *v;
         if (get(h, p + "self_attn.pos_bias_u", {kHeads, kDk}, &u) || get(h, p + "self_attn.pos_bias_v", {kHeads, kDk}, &v)) return 1;
-        if (make_lin(h, &b.qu, p + "self_attn.linear_q", kD, kD, 1, true, u->v.data())) return 1;
-        if (make_lin(h, &b.qv, p + "self_attn.linear_q", kD, kD, 1, true, v->v.data(), b.qu.wt)) return 1;
-        if (make_lin(h, &b.k, p + "self_attn.linear_k", kD, kD, 1, true)) return 1;
-        if (make_lin(h, &b.v, p + "self_attn.linear_v", kD, kD, 1, true)) return 1;
+        {
+            // rows 0..511 linear_q with pos_bias_u added to the bias, 512..1023 linear_q with pos_bias_v, then linear_k, linear_v
+            const Host *wq, *bq, *wk, *bk, *wv, *bv;
+            if (get(h, p + "self_attn.linear_q.weight", {kD, kD}, &wq) || get(h, p + "self_attn.linear_q.bias", {kD}, &bq)) return 1;
+            if (get(h, p + "self_attn.linear_k.weight", {kD, kD}, &wk) || get(h, p + "self_attn.linear_k.bias", {kD}, &bk)) return 1;
+            if (get(h, p + "self_attn.linear_v.weight", {kD, kD}, &wv) || get(h, p + "self_attn.linear_v.bias", {kD}, &bv)) return 1;
+            std::vector<float> wst((size_t)4 * kD * kD), bst(4 * kD);
+            for (int part = 0; part < 4; ++part) {
+                const Host* ws = part < 2 ? wq : (part == 2 ? wk : wv);
+                const Host* bs = part < 2 ? bq : (part == 2 ? bk : bv);
+                std::copy(ws->v.begin(), ws->v.end(), wst.begin() + (size_t)part * kD * kD);
+                for (int i = 0; i < kD; ++i)
+                    bst[part * kD + i] = bs->v[i] + (part == 0 ? u->v[i] : (part == 1 ? v->v[i] : 0.f));
+            }
+            const std::vector<float> t = s3_tile_conv_weights(wst.data(), 4 * kD, kD, 1);
+            b.qkv.Cin = kD; b.qkv.Cout = 4 * kD; b.qkv.K = 1;
+            if (upload(h, &b.qkv.wt, t.data(), t.size()) || upload(h, &b.qkv.bias, bst.data(), bst.size())) return 1;
+        }
         if (make_lin(h, &b.pos, p + "self_attn.linear_pos", kD, kD, 1, false)) return 1;
         if (make_lin(h, &b.out, p + "self_attn.linear_out", kD, kD, 1, true)) return 1;
         if (make_lin(h, &b.w1, p + "feed_forward.w_1", kFfn, kD, 1, true)) return 1;
@@ -398,8 +417,10 @@ extern "C" int s3flow_enc_finalize(s3flow_enc* h) {
     for (int i = 0; i < kD / 2; ++i) div[i] = std::exp((float)(2 * i) * step);
     if (upload(h, &h->div_term, div.data(), div.size())) return 1;
     const size_t Tm = 2 * (size_t)h->max_tokens, act = (size_t)kD * h->ld;
-    for (float** p : {&h->X, &h->N, &h->QU, &h->QV, &h->Kb, &h->Vb, &h->O, &h->HID, &h->U})
+    for (float** p : {&h->X, &h->N, &h->O, &h->HID, &h->U})
         if (dalloc(h, p, act)) return 1;
+    if (dalloc(h, &h->QU, 4 * act)) return 1;               // the stacked projection's output: q + u, q + v, k, v
+    h->QV = h->QU + act; h->Kb = h->QU + 2 * act; h->Vb = h->QU + 3 * act;
     if (dalloc(h, &h->H, (size_t)kFfn * h->ld)) return 1;
     if (dalloc(h, &h->PE, (size_t)kD * h->ldp) || dalloc(h, &h->P, (size_t)kD * h->ldp)) return 1;
     if (dalloc(h, &h->Sac, (size_t)kHeads * Tm * Tm) || dalloc(h, &h->Sbd, (size_t)kHeads * Tm * (2 * Tm))) return 1;

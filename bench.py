@@ -253,12 +253,28 @@ def vocoder_leg(device, batch=8, frames=500, iters=5):
     pre, stages, post = HW.decode_flop(frames)
     flop = batch * (pre + sum(stages) + post)
     achieved = flop / (ev_ms * 1e-3) / 1e12
+    # HBM bytes per call from the committed counter passes, quoted only for the kernel sources they were taken on
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "hift_pmc_traffic.json")) as fh:
+            prof = json.load(fh)
+        h = hashlib.sha256()
+        d = os.path.join(ROOT, "chatterbox_vllm_amd", "csrc_s3gen")
+        for name in sorted(os.listdir(d)):
+            if name.endswith((".hip", ".h")):
+                with open(os.path.join(d, name), "rb") as fh:
+                    h.update(fh.read())
+        if prof.get("kernel_source_sha16") == h.hexdigest()[:16] and (batch, frames) == (8, 500):
+            traffic = prof["bytes_per_call"]
+    except (OSError, ValueError, KeyError):
+        pass
     rec = {"workload": f"S3Gen HiFT vocoder, decode() of {batch} utterances x {frames} mel frames ({frames * 0.02:.0f} s each), seeded synthetic weights",
            "metric": "audio seconds per second", "value": round(batch * frames * 0.02 / wall, 1), "unit": "audio s/s",
            "ms_per_step": round(wall * 1e3, 3), "inference_value": round(batch * frames * 0.02 / wall_inf, 1), "dtype": "f32",
            "roofline": {"bound": "mfma", "kernel": "conv1d_kernel (74 launches of a call)", "achieved": round(achieved, 2),
                         "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-                        "traffic": None, "event_ms_per_call": round(ev_ms, 3), "algorithmic_gflop_per_call": round(flop / 1e9, 1),
+                        "traffic": traffic, "traffic_unit": "HBM bytes per call (committed rocprofv3 --pmc passes)",
+                        "event_ms_per_call": round(ev_ms, 3), "algorithmic_gflop_per_call": round(flop / 1e9, 1),
                         "stage_ms": [round(sum(e[i] for e in ev) / len(ev), 3) for i in range(5)]}}
     from oracle import hift_oracle as HO
     w = HO.fold_weight_norm(sd)

@@ -14,6 +14,7 @@
 #include "hift_common.h"
 #include "../../include/s3flow_hip.h"
 
+#include <algorithm>
 #include <cmath>
 #include <map>
 #include <vector>
@@ -250,26 +251,19 @@ int get(s3flow_enc* h, const std::string& name, std::initializer_list<int64_t> s
     *out = &it->second;
     return 0;
 }
-// Linear [Cout, Cin] or Conv1d [Cout, Cin, K] -> tile order; `extra` (may be null) is added to the bias; no bias tensor = zeros
-int make_lin(s3flow_enc* h, Lin* l, const std::string& name, int Cout, int Cin, int K, bool has_bias, const float* extra = nullptr,
-             const float* shared_wt = nullptr) {
+// Linear [Cout, Cin] or Conv1d [Cout, Cin, K] -> tile order; no bias tensor = zeros
+int make_lin(s3flow_enc* h, Lin* l, const std::string& name, int Cout, int Cin, int K, bool has_bias) {
     const Host* w;
     if (K == 1 ? get(h, name + ".weight", {Cout, Cin}, &w) : get(h, name + ".weight", {Cout, Cin, K}, &w)) return 1;
     l->Cin = Cin; l->Cout = Cout; l->K = K;
-    if (shared_wt) {
-        l->wt = const_cast<float*>(shared_wt);
-    } else {
-        const std::vector<float> t = s3_tile_conv_weights(w->v.data(), Cout, Cin, K);
-        if (upload(h, &l->wt, t.data(), t.size())) return 1;
-    }
+    const std::vector<float> t = s3_tile_conv_weights(w->v.data(), Cout, Cin, K);
+    if (upload(h, &l->wt, t.data(), t.size())) return 1;
     std::vector<float> b(Cout, 0.f);
     if (has_bias) {
         const Host* bt;
         if (get(h, name + ".bias", {Cout}, &bt)) return 1;
         b = bt->v;
     }
-    if (extra)
-        for (int i = 0; i < Cout; ++i) b[i] += extra[i];
     return upload(h, &l->bias, b.data(), Cout);
 }
 int vec(s3flow_enc* h, float** dst, const std::string& name, int n) {

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--frames", type=int, default=500)
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--decode-only", action="store_true", help="one warm-up decode and `iters` timed ones, nothing else (counter passes)")
     args = ap.parse_args()
     B, T = args.batch, args.frames
     gen = HiFTGenerator(HW.synthetic_state_dict(), max_batch=B, max_frames=T)
@@ -34,6 +35,10 @@ def main():
         wav = gen.decode(mel, s)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.iters
+    if args.decode_only:
+        print(json.dumps({"batch": B, "frames": T, "decode_ms": round(dt * 1e3, 3), "decode_calls": args.iters + 1}))
+        gen.shutdown()
+        return
     gen.set_timing(True)
     gen.decode(mel, s)
     stage_ms = gen.last_timing()

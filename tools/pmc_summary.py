@@ -13,7 +13,7 @@ cnt = defaultdict(lambda: defaultdict(int))
 for f in files:
     with open(f) as fh:
         for r in csv.DictReader(fh):
-            k = r["Kernel_Name"].split("(")[0][:72]
+            k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0][:72]
             c = r["Counter_Name"]
             tot[c][k] += float(r["Counter_Value"])
             cnt[c][k] += 1
@@ -24,6 +24,7 @@ for c in tot:
         mean_kib = tot[c][k] / cnt[c][k]
         b = mean_kib * 1024.0
         out[c][k] = {"dispatches": cnt[c][k], "mean_KiB": round(mean_kib, 3),
-                     "bytes_corrected": round(b * (2.0 if c == "FETCH_SIZE" else 1.0), 1)}
+                     "bytes_corrected": round(b * (2.0 if c == "FETCH_SIZE" else 1.0), 1),
+                     "total_bytes_corrected": round(b * cnt[c][k] * (2.0 if c == "FETCH_SIZE" else 1.0), 1)}
 json.dump(out, sys.stdout, indent=1)
 print()

@@ -17,4 +17,12 @@ timeout -s KILL 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_
     -d /tmp/ph_m -o m --output-format csv -- \
     python3 $R/tools/bench_hift.py --batch 8 --frames 500 --iters 2 > $OUT/${TAG}_hift_pmc_bench.json 2>> $OUT/${TAG}_hift_rocprof_stderr.log || exit 1
 python3 $R/tools/mfma_summary.py /tmp/ph_m > $OUT/${TAG}_hift_pmc_mfma.json || exit 1
+#   3. HBM traffic: FETCH_SIZE and WRITE_SIZE in separate passes (they do not fit one) over one warm-up + one decode call
+rm -rf /tmp/ph_f /tmp/ph_w
+timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE -d /tmp/ph_f -o f --output-format csv -- \
+    python3 $R/tools/bench_hift.py --batch 8 --frames 500 --iters 1 --decode-only > $OUT/${TAG}_hift_pmc_fetch_bench.json 2>> $OUT/${TAG}_hift_rocprof_stderr.log || exit 1
+python3 $R/tools/pmc_summary.py /tmp/ph_f > $OUT/${TAG}_hift_pmc_fetch.json || exit 1
+timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE -d /tmp/ph_w -o w --output-format csv -- \
+    python3 $R/tools/bench_hift.py --batch 8 --frames 500 --iters 1 --decode-only > $OUT/${TAG}_hift_pmc_write_bench.json 2>> $OUT/${TAG}_hift_rocprof_stderr.log || exit 1
+python3 $R/tools/pmc_summary.py /tmp/ph_w > $OUT/${TAG}_hift_pmc_write.json || exit 1
 echo done

@@ -1,0 +1,124 @@
+"""Flow-matching decoder of S3Gen's flow stage on the GPU: the host-side mirror of the reference's
+``CausalConditionalCFM`` (src/chatterbox_vllm/models/s3gen/flow_matching.py:198-228) with its ``ConditionalDecoder``
+estimator (decoder.py:100-317), over the C ABI of include/s3cfm_hip.h (entry points in ``lib/libs3hift.so``).
+
+``CausalConditionalCFM(state_dict)(mu=, mask=, spks=, cond=, n_timesteps=)`` takes and returns what the reference module's
+``forward`` does, so it is the ``decoder`` that ``S3Token2Wav`` calls.  fp32 on the handle's GPU; torch carries device memory
+only."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import cfm_weights as CW
+from .hift import HiftError, check, load, _P, _ptr, _stream_ptr
+
+_SIGNATURES = {
+    "s3cfm_create": ([C.c_int32, C.c_int32, C.POINTER(_P)], C.c_int),
+    "s3cfm_destroy": ([_P], C.c_int),
+    "s3cfm_load_tensor": ([_P, C.c_char_p, _P, C.POINTER(C.c_int64), C.c_int32], C.c_int),
+    "s3cfm_finalize": ([_P], C.c_int),
+    "s3cfm_estimator": ([_P, _P, _P, _P, _P, C.c_float, C.c_int32, _P, _P], C.c_int),
+    "s3cfm_solve": ([_P, _P, _P, _P, _P, C.c_int32, C.POINTER(C.c_float), C.c_int32, C.c_double, _P, _P], C.c_int),
+}
+
+
+def _lib() -> C.CDLL:
+    lib = load()
+    if not getattr(lib, "_s3cfm_declared", False):
+        for name, (argtypes, restype) in _SIGNATURES.items():
+            if not hasattr(lib, name):
+                raise HiftError(f"libs3hift.so does not export {name}: rebuild it (make -C chatterbox_vllm_amd/csrc_s3gen)")
+            fn = getattr(lib, name)
+            fn.argtypes, fn.restype = argtypes, restype
+        lib._s3cfm_declared = True
+    return lib
+
+
+class CausalConditionalCFM:
+    """``state_dict`` holds ``S3Token2Wav.flow.state_dict()`` (only the ``decoder.estimator.*`` entries are taken).
+
+    ``rand_noise`` is the fixed noise the reference draws once at construction (``torch.randn([1, 80, 50 * 300])``,
+    flow_matching.py:201) and slices per utterance; it is drawn the same way here, from torch's global CPU generator
+    unless one is passed."""
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor], max_frames: int = 3000, device: int = 0,
+                 inference_cfg_rate: float = CW.CFG_RATE, generator: Optional[torch.Generator] = None):
+        self._lib = _lib()
+        self.device = torch.device("cuda", device)
+        self.max_frames = max_frames
+        self.inference_cfg_rate = inference_cfg_rate
+        self.rand_noise = torch.randn([1, CW.MEL, CW.NOISE_FRAMES], generator=generator)
+        self._noise_dev = None
+        h = _P()
+        check(self._lib, self._lib.s3cfm_create(device, max_frames, C.byref(h)))
+        self._h = h
+        try:
+            for name, _ in CW.tensor_inventory():
+                if name not in state_dict:
+                    raise KeyError(f"state dict lacks {name}")
+                t = state_dict[name].detach().to("cpu", torch.float32).contiguous()
+                shape = (C.c_int64 * t.dim())(*t.shape)
+                check(self._lib, self._lib.s3cfm_load_tensor(h, name.encode(), C.c_void_p(t.data_ptr()), shape, t.dim()))
+            check(self._lib, self._lib.s3cfm_finalize(h))
+        except Exception:
+            self.shutdown()
+            raise
+
+    def _check_len(self, L: int) -> None:
+        if L < 1 or L > self.max_frames:
+            raise ValueError(f"{L} mel frames exceed the workspace ({self.max_frames})")
+
+    def estimator(self, x: torch.Tensor, mu: torch.Tensor, t: float, spks: torch.Tensor, cond: torch.Tensor) -> torch.Tensor:
+        """``ConditionalDecoder.forward`` on two rows with one time value: x, mu, cond [2, 80, L], spks [2, 80] -> [2, 80, L]."""
+        f = lambda a: a.to(self.device, torch.float32).contiguous()
+        x, mu, spks, cond = f(x), f(mu), f(spks), f(cond)
+        L = x.shape[2]
+        self._check_len(L)
+        assert x.shape == (2, CW.MEL, L) and mu.shape == x.shape and cond.shape == x.shape and spks.shape == (2, CW.MEL)
+        out = torch.empty_like(x)
+        check(self._lib, self._lib.s3cfm_estimator(self._h, _ptr(x), _ptr(mu), _ptr(spks), _ptr(cond), float(t), L, _ptr(out),
+                                                   _stream_ptr(self.device)))
+        return out
+
+    def solve_euler(self, z: torch.Tensor, t_span: torch.Tensor, mu: torch.Tensor, spks: torch.Tensor, cond: torch.Tensor) -> torch.Tensor:
+        """flow_matching.py:82-133 for one utterance: z, mu, cond [1, 80, L], spks [1, 80], t_span [n + 1] -> [1, 80, L]."""
+        f = lambda a: a.to(self.device, torch.float32).contiguous()
+        z, mu, spks, cond = f(z), f(mu), f(spks), f(cond)
+        L = mu.shape[2]
+        self._check_len(L)
+        assert mu.shape == (1, CW.MEL, L) and z.shape == mu.shape and cond.shape == mu.shape and spks.shape == (1, CW.MEL)
+        ts = t_span.detach().to("cpu", torch.float32).contiguous()
+        n = ts.numel() - 1
+        grid = (C.c_float * (n + 1))(*ts.tolist())
+        mel = torch.empty_like(mu)
+        check(self._lib, self._lib.s3cfm_solve(self._h, _ptr(mu), _ptr(spks), _ptr(cond), _ptr(z), L, grid, n,
+                                               float(self.inference_cfg_rate), _ptr(mel), _stream_ptr(self.device)))
+        return mel
+
+    @torch.inference_mode()
+    def forward(self, mu: torch.Tensor, mask: Optional[torch.Tensor] = None, n_timesteps: int = 10, temperature: float = 1.0,
+                spks: Optional[torch.Tensor] = None, cond: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, None]:
+        """flow_matching.py:203-228.  ``mask`` must be all ones (one utterance, as flow.py:278 builds it)."""
+        L = mu.shape[2]
+        if L > self.rand_noise.shape[2]:
+            raise ValueError(f"{L} mel frames exceed the fixed noise buffer ({self.rand_noise.shape[2]})")
+        if self._noise_dev is None:
+            self._noise_dev = self.rand_noise.to(self.device)
+        z = self._noise_dev[:, :, :L] * temperature
+        return self.solve_euler(z, CW.t_span(n_timesteps), mu, spks, cond), None
+
+    __call__ = forward
+
+    def shutdown(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.s3cfm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.shutdown()
+        except Exception:
+            pass

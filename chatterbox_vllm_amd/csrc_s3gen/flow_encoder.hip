@@ -89,20 +89,15 @@ __global__ void upsample2_kernel(const float* __restrict__ x, int ldx, float* __
     if (j < T2) y[(size_t)c * ldy + j] = x[(size_t)c * ldx + (j >> 1)];
 }
 
-// C[b](m, n) = sum_k A[b](m, k) * B[b](k, n), fp32 on v_mfma_f32_32x32x2_f32; operands addressed by strides (elements),
-// 64 x 64 output tile per workgroup (one 32 x 32 accumulator per wave), k in steps of 16 through LDS
-struct BGemm {
-    const float* A; long long a_bs, sam, sak;
-    const float* B; long long b_bs, sbk, sbn;
-    float* C; long long c_bs, ldc;
-    int M, N, K;
-};
+// BGemm (hift_common.h) on v_mfma_f32_32x32x2_f32: 64 x 64 output tile per workgroup (one 32 x 32 accumulator per wave),
+// k in steps of 16 through LDS
 __global__ __launch_bounds__(256) void bgemm_kernel(BGemm g) {
     __shared__ float As[2][16][96], Bs[2][16][96];            // rows 32 banks apart modulo 64
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w & 1, wn = w >> 1;
     const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
-    const float* A = g.A + (size_t)blockIdx.z * g.a_bs;
-    const float* B = g.B + (size_t)blockIdx.z * g.b_bs;
+    const long long z1 = g.zdiv ? blockIdx.z / g.zdiv : 0, z0 = g.zdiv ? blockIdx.z % g.zdiv : blockIdx.z;
+    const float* A = g.A + z1 * g.a_bs2 + z0 * g.a_bs;
+    const float* B = g.B + z1 * g.b_bs2 + z0 * g.b_bs;
     const bool a_m_fast = g.sam == 1, b_n_fast = g.sbn == 1;  // which index consecutive threads walk
     float ra[4], rb[4];
     auto load = [&](int k0) {
@@ -144,7 +139,7 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BGemm g) {
         if (ch + 1 < nchunk) store(buf ^ 1);
         __syncthreads();
     }
-    float* C = g.C + (size_t)blockIdx.z * g.c_bs;
+    float* C = g.C + z1 * g.c_bs2 + z0 * g.c_bs;
     const int n = n0 + wn * 32 + (lane & 31);
     if (n >= g.N) return;
 #pragma unroll
@@ -292,11 +287,7 @@ int run_ln(const float* x, int ldx, float* y, int ldy, int T, const float* g, co
     return 0;
 }
 
-int run_bgemm(const BGemm& g, int batch, hipStream_t st) {
-    hipLaunchKernelGGL(bgemm_kernel, dim3((g.M + 63) / 64, (g.N + 63) / 64, batch), dim3(256), 0, st, g);
-    S3_HIP_CHECK(hipGetLastError());
-    return 0;
-}
+int run_bgemm(const BGemm& g, int batch, hipStream_t st) { return launch_bgemm(g, batch, st); }
 
 // ConformerEncoderLayer.forward (transformer/encoder_layer.py:191-235) on X [512][T]
 int run_block(s3flow_enc* h, const Block& b, int T, hipStream_t st) {
@@ -326,6 +317,12 @@ int run_pos_emb(s3flow_enc* h, int T, hipStream_t st) {
 }
 
 }  // namespace
+
+int launch_bgemm(const BGemm& g, int batch, hipStream_t st) {
+    hipLaunchKernelGGL(bgemm_kernel, dim3((g.M + 63) / 64, (g.N + 63) / 64, batch), dim3(256), 0, st, g);
+    S3_HIP_CHECK(hipGetLastError());
+    return 0;
+}
 
 extern "C" int s3flow_enc_create(int32_t device, int32_t max_tokens, s3flow_enc** out) {
     S3_REQUIRE(out && max_tokens >= 1 && max_tokens <= 8192, "bad arguments");

@@ -1,0 +1,53 @@
+/* C ABI of the flow-matching decoder of S3Gen's flow stage (mu -> mel) on MI355X (gfx950); the entry points live in
+ * libs3hift.so next to the vocoder's (include/s3hift_hip.h) and the token -> mu encoder's (include/s3flow_hip.h).
+ *
+ * It replaces the `self.decoder(mu=..., mask=..., spks=..., cond=..., n_timesteps=...)` call of the reference's
+ * `CausalMaskedDiffWithXvec.inference` (src/chatterbox_vllm/models/s3gen/flow.py:279-285): `CausalConditionalCFM.forward`
+ * (flow_matching.py:203-228), its Euler solver with classifier-free guidance (`ConditionalCFM.solve_euler`, :82-133) and the
+ * estimator it calls twice per step, `ConditionalDecoder.forward` (decoder.py:233-317; built by s3gen.py:76-87 with 320 input
+ * rows, 256 channels, one down stage, twelve mid stages, one up stage, four transformer blocks of 8 heads x 64 per stage).
+ * One utterance per call (the reference asserts batch 1, flow.py:256), all masks ones, full attention
+ * (`static_chunk_size` is 0, decoder.py:135).  All arithmetic is fp32, as in the reference.
+ *
+ * Plain pointers and sizes only.  *_dev pointers are device memory on the handle's GPU; every function returns 0 on
+ * success, s3hift_last_error() (s3hift_hip.h) describes a failure.  Calls on one handle must not overlap.  Kernels are
+ * enqueued on `stream` (hipStream_t, NULL = the null stream); only create / finalize / destroy synchronise. */
+#ifndef S3CFM_HIP_H
+#define S3CFM_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define S3CFM_MEL 80
+#define S3CFM_MAX_FRAMES 8192
+
+typedef struct s3cfm s3cfm;
+
+/* Workspace for utterances of up to max_frames mel frames (prompt + new; two per speech token). */
+int s3cfm_create(int32_t device, int32_t max_frames, s3cfm** out);
+int s3cfm_destroy(s3cfm* h);
+
+/* One tensor of `S3Token2Wav.flow.state_dict()` whose name starts with `decoder.estimator.`, fp32 host memory, PyTorch
+ * shapes. */
+int s3cfm_load_tensor(s3cfm* h, const char* name, const float* host_data, const int64_t* shape, int32_t ndim);
+int s3cfm_finalize(s3cfm* h);
+
+/* One estimator call, `ConditionalDecoder.forward(x, mask, mu, t, spks, cond)` (decoder.py:233-317) on two rows:
+ * x_dev, mu_dev, cond_dev [2][80][L], spks_dev [2][80], the same time t for both rows (as solve_euler calls it,
+ * flow_matching.py:116) -> out_dev [2][80][L]. */
+int s3cfm_estimator(s3cfm* h, const float* x_dev, const float* mu_dev, const float* spks_dev, const float* cond_dev, float t,
+                    int32_t L, float* out_dev, void* stream);
+
+/* `CausalConditionalCFM.forward` (flow_matching.py:203-228): mu_dev [80][L], spks_dev [80], cond_dev [80][L] (the prompt's
+ * mel frames, then zeros), noise_dev [80][L] (the leading columns of the module's `rand_noise` buffer, already multiplied
+ * by the temperature) -> mel_dev [80][L].  t_span is host memory, n_timesteps + 1 values: the time grid of :225-227, which
+ * the caller computes (chatterbox_vllm_amd/cfm_weights.py does it with the reference's own torch operations); cfg_rate is
+ * `inference_cfg_rate` (0.7, flow_matching.py:26), a double as in the reference: 1 + rate is formed before rounding to fp32. */
+int s3cfm_solve(s3cfm* h, const float* mu_dev, const float* spks_dev, const float* cond_dev, const float* noise_dev, int32_t L,
+                const float* t_span, int32_t n_timesteps, double cfg_rate, float* mel_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -107,12 +107,13 @@ def test_inference_matches_the_reference(fx, w):
 
 
 def test_library_loads_and_exports_every_declared_symbol():
-    """libs3hift.so exports every function include/s3hift_hip.h and include/s3flow_hip.h declare, and the bindings declare
-    the same sets."""
+    """libs3hift.so exports every function include/s3hift_hip.h, include/s3flow_hip.h and include/s3cfm_hip.h declare, and
+    the bindings declare the same sets."""
     import re
-    from chatterbox_vllm_amd import flow_encoder, hift
+    from chatterbox_vllm_amd import cfm_decoder, flow_encoder, hift
     lib = C.CDLL(hift.lib_path())
-    for header, prefix, sigs in (("s3hift_hip.h", "s3hift_", hift._SIGNATURES), ("s3flow_hip.h", "s3flow_", flow_encoder._SIGNATURES)):
+    for header, prefix, sigs in (("s3hift_hip.h", "s3hift_", hift._SIGNATURES), ("s3flow_hip.h", "s3flow_", flow_encoder._SIGNATURES),
+                                 ("s3cfm_hip.h", "s3cfm_", cfm_decoder._SIGNATURES)):
         text = open(os.path.join(ROOT, "include", header)).read()
         declared = set(re.findall(r"\b(" + prefix + r"[a-z0-9_]+)\s*\(", text))
         assert declared == set(sigs), declared ^ set(sigs)

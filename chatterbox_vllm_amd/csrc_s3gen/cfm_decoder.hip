@@ -4,22 +4,26 @@
 // 203-228, 82-133) around ConditionalDecoder.forward (decoder.py:233-317).  Every Euler step runs the estimator on two rows
 // (conditioned, unconditioned) of the same x.  Activations are channel-major, [row][channel][frame] fp32, the layout of the
 // vocoder's tensors: the causal convolutions and every Linear go through the matrix kernel of hift_kernels.hip (weights as
-// the A operand, frames as N, a Linear being a one-tap convolution), residual adds ride in its epilogue and the GELU of the
-// feed-forward is applied while its input tile is staged.  LayerNorm over the 256 channels of a frame, with the Mish and the
-// time-embedding add that follow it in a resnet block, is one small kernel.  Attention (8 heads x 64) is the three-launch
-// form of flow_encoder.hip: scores, row softmax, weighted sum of values on the strided fp32 matrix kernel.
+// the A operand, frames as N, a Linear being a one-tap convolution) or, by default, through lin_kernel below, a variant of it
+// shaped for the few output tiles of one utterance; residual adds and the GELU of the feed-forward ride in the epilogue.  LayerNorm over the 256 channels of a frame, with the Mish and the
+// time-embedding add that follow it in a resnet block, is one small kernel.  Attention (8 heads x 64) is one launch with an
+// online softmax (attn_kernel).
 #include "hift_common.h"
 #include "../../include/s3cfm_hip.h"
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <map>
 #include <vector>
 
 namespace {
 
-constexpr int kMel = S3CFM_MEL, kIn = 4 * S3CFM_MEL, kC = 256, kTime = 1024, kHeads = 8, kDk = 64, kInner = 512, kFf = 1024;
+constexpr int kMel = S3CFM_MEL, kIn = 4 * S3CFM_MEL, kC = 256, kTime = 1024, kHeads = 8, kInner = 512, kFf = 1024;
 constexpr int kBlocks = 4, kMid = 12, kStages = kMid + 2, kRows = 2;
+// Row strides are odd multiples of 256 bytes: a tile's rows (64 channels of K, 32 frames of V) then spread over the L2
+// channels instead of landing on one or two of them, which strides of 2 or 4 KiB would do.
+constexpr int kVtLd = kInner + 64;
 
 // ---- kernels -----------------------------------------------------------------------------------------------------
 
@@ -105,33 +109,220 @@ __global__ __launch_bounds__(256) void gemv_kernel(const float* __restrict__ W, 
     }
 }
 
-// a[z][i][:] = softmax_j(s[z][i][j] / 8), in place
-__global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ s, int T) {
-    __shared__ float red[4];
-    const int tid = threadIdx.x;
-    float* row = s + ((long long)blockIdx.y * T + blockIdx.x) * T;
-    float mx = -INFINITY;
-    for (int j = tid; j < T; j += 256) {
-        const float v = row[j] * 0.125f;
-        row[j] = v;
-        mx = fmaxf(mx, v);
+// Self-attention of one transformer block, 8 heads x 64, all frames attend to all frames (the diffusers default attention
+// processor: softmax(q k^T / 8) v).  One workgroup per (32 queries, head, row); its four waves take every fourth 32-key tile
+// and run an online softmax each, and their partial (max, sum, output) triples are merged through LDS in wave order.
+// Scores are computed transposed, S^T[key][query] = sum_d K[d][key] Q[d][query], so that a lane owns one query column: the
+// softmax statistics are per lane (one exchange between the two halves of the wave), the probabilities sit in the accumulator
+// layout that the second product wants as its B operand, and O^T[d][query] += V[d][key] P^T[key][query] takes V frame-major
+// ([frame][512], written that way by the q/k/v projection) so that its A operand is 32 consecutive floats per key.
+// K and V tiles come straight from global memory (L2 hits after the first pass, see the workgroup order); Q lives in registers.
+struct AttnArgs {
+    const float* q; const float* k; size_t qk_bs; int ld;     // [row][512][ld] channel-major, head h at channels 64 h ..
+    const float* vt; size_t vt_bs;                            // [row][L][kVtLd] frame-major
+    float* o; size_t o_bs;                                    // [row][512][ld]
+    int L;
+};
+__global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
+    __shared__ float so[4 * 32 * 64];
+    __shared__ float sm[4][64], sl[4][64];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, half = lane >> 5, col = lane & 31;
+    // workgroup i runs on XCD i % 8: give each XCD two of the sixteen (row, head) pairs, so that the K and V it streams
+    // (0.5 KiB per frame and pair) stay in its own L2
+    const int pair = (blockIdx.x & 7) * 2 + ((blockIdx.x >> 3) & 1), qt = blockIdx.x >> 4;
+    const int qn = qt * 32 + col, b = pair >> 3, h = pair & 7;
+    const float* qp = a.q + b * a.qk_bs + (size_t)(h * 64 + half) * a.ld + (qn < a.L ? qn : a.L - 1);
+    float Q[32];
+#pragma unroll
+    for (int kk = 0; kk < 32; ++kk) Q[kk] = qp[(size_t)(2 * kk) * a.ld] * 0.125f;
+    f32x16 o0, o1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
+    float m = -INFINITY, l = 0.f;
+    const float* kbase = a.k + b * a.qk_bs + (size_t)(h * 64 + half) * a.ld;
+    const float* vbase = a.vt + b * a.vt_bs + h * 64 + col;
+    const int ntiles = (a.L + 31) / 32;
+    // A tile's 32 K loads are issued a whole tile ahead (right after the score products that free their registers), its 32 V
+    // loads before the score products; the scheduling barriers keep the compiler from sinking each load next to its use,
+    // which would leave one load in flight at a time.
+    float kr[32], v0[16], v1[16];
+    auto load_k = [&](int t) {
+        const int kc = t * 32 + col;
+        const float* kp = kbase + (kc < a.L ? kc : a.L - 1);
+#pragma unroll
+        for (int kk = 0; kk < 32; ++kk) kr[kk] = kp[(size_t)(2 * kk) * a.ld];
+    };
+    if (w < ntiles) load_k(w);
+    for (int t = w; t < ntiles; t += 4) {
+        const int key0 = t * 32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = key0 + 8 * (r >> 2) + 4 * half + (r & 3);
+            const float* vp = vbase + (size_t)(key < a.L ? key : a.L - 1) * kVtLd;
+            v0[r] = vp[0];
+            v1[r] = vp[32];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 s;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[i] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 32; ++kk) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kr[kk], Q[kk], s, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_k(t + 4 < ntiles ? t + 4 : t);                    // the last tile loads itself again: no branch to schedule around
+        __builtin_amdgcn_sched_barrier(0);
+        // accumulator r of a lane: key key0 + 8 (r / 4) + 4 (lane / 32) + r % 4, query lane % 32
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = key0 + 8 * (r >> 2) + 4 * half + (r & 3);
+            if (key >= a.L) s[r] = -INFINITY;
+            mx = fmaxf(mx, s[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m, mx);                      // finite: every tile holds a key below L
+        const float alpha = expf(m - m_new);
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = expf(s[r] - m_new); ps += s[r]; }
+        ps += __shfl_xor(ps, 32);
+        l = l * alpha + ps;
+        m = m_new;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0[r], s[r], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1[r], s[r], o1, 0, 0, 0);
+        }
     }
-    for (int off = 32; off; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
-    if ((tid & 63) == 0) red[tid >> 6] = mx;
-    __syncthreads();
-    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    __syncthreads();
-    float sum = 0.f;
-    for (int j = tid; j < T; j += 256) {
-        const float e = expf(row[j] - mx);
-        row[j] = e;
-        sum += e;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        so[(w * 32 + r) * 64 + lane] = o0[r];
+        so[(w * 32 + 16 + r) * 64 + lane] = o1[r];
     }
-    for (int off = 32; off; off >>= 1) sum += __shfl_xor(sum, off);
-    if ((tid & 63) == 0) red[tid >> 6] = sum;
+    sm[w][lane] = m;
+    sl[w][lane] = l;
     __syncthreads();
-    const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
-    for (int j = tid; j < T; j += 256) row[j] = row[j] * inv;
+    const float ms = fmaxf(fmaxf(sm[0][lane], sm[1][lane]), fmaxf(sm[2][lane], sm[3][lane]));
+    float f[4], lsum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[i] = expf(sm[i][lane] - ms); lsum += f[i] * sl[i][lane]; }   // a wave without tiles: exp(-inf) = 0
+    const float inv = 1.0f / lsum;
+    if (qn >= a.L) return;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int r = w * 8 + i;                               // this wave finishes a quarter of the 64 output channels
+        float v = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v += so[(j * 32 + r) * 64 + lane] * f[j];
+        const int d = (r >> 4) * 32 + 8 * ((r & 15) >> 2) + 4 * half + (r & 3);
+        a.o[b * a.o_bs + (size_t)(h * 64 + d) * a.ld + qn] = v * inv;
+    }
+}
+
+// Linear layers and causal convolutions of the estimator: y[z][co][n] = out_act(bias[co] + sum_{tap, ci} W[co][ci][tap] *
+// x[z][ci][n + tap - pad]) (+ res[z][co][n]); x outside [0, L) reads as zero.  The utterances here are short (N of a few
+// hundred to a few thousand frames against 256 .. 1536 output channels), so a launch has few output tiles and the kernel
+// is built for many small workgroups rather than deep tiles: a wave owns 64 channels x 32 frames (two 32 x 32
+// accumulators sharing their B operand), takes its weights in tile order straight from L2 (one 16-byte load per lane per
+// 8 input channels) and its x operand straight from the channel-major tensor (lanes 0-31 read 32 consecutive frames of
+// one channel, lanes 32-63 of the next: two 128-byte segments per load), PF steps ahead in registers; nothing is staged
+// in LDS.  KSPLIT = 4: the four waves of a workgroup split the reduction over (tap, ci) in contiguous quarters and their
+// partial sums meet in LDS in a fixed order; KSPLIT = 1: the waves take four neighbouring 32-frame tiles instead.
+struct LinArgs {
+    const float* x; size_t x_bs; int x_ld;
+    const float* wt; const float* bias;      // wt in tile order (ConvArgs::wt)
+    float* y; size_t y_bs; int y_ld;
+    const float* res;                        // layout of y; may be y itself
+    float* yt; size_t yt_bs; int yt_ld, yt_from;   // yt not null: channels >= yt_from go to yt[z][n][co - yt_from] (frame-major)
+    int Cin, Cout, CoutPad, K, pad, L;
+};
+enum { OUT_NONE = 0, OUT_GELU = 1 };
+
+template <int KSPLIT, int OUT_ACT>
+__global__ __launch_bounds__(256) void lin_kernel(LinArgs a) {
+    constexpr int PF = 4;
+    __shared__ float part[KSPLIT == 4 ? 4 * 32 * 64 : 1];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, half = lane >> 5;
+    const int n = (KSPLIT == 4 ? blockIdx.x * 32 : blockIdx.x * 128 + 32 * w) + (lane & 31);
+    const int cb0 = blockIdx.y * 2, z = blockIdx.z;
+    const int g8 = a.Cin / 8, steps = a.K * g8;
+    const int ns = KSPLIT == 4 ? steps / 4 : steps, s0 = KSPLIT == 4 ? w * ns : 0;
+    const bool live1 = (cb0 + 1) * 32 < a.CoutPad;
+    const f32x4* __restrict__ w0 = reinterpret_cast<const f32x4*>(a.wt) + (size_t)cb0 * steps * 64 + lane;
+    const f32x4* __restrict__ w1 = reinterpret_cast<const f32x4*>(a.wt) + (size_t)(live1 ? cb0 + 1 : cb0) * steps * 64 + lane;
+    const float* __restrict__ xb = a.x + z * a.x_bs + (size_t)half * a.x_ld;
+
+    f32x4 A0[PF], A1[PF];
+    float B[PF][4];
+    auto load = [&](int slot, int s) {                         // s: step index of this wave, (tap, g) = divmod(s0 + s, g8)
+        const int sg = s0 + s, tap = sg / g8, g = sg - tap * g8;
+        A0[slot] = w0[(size_t)sg * 64];
+        A1[slot] = w1[(size_t)sg * 64];
+        const int col = n + tap - a.pad;
+        const bool ok = col >= 0 && col < a.L;
+        const float* xp = xb + (size_t)(g * 8) * a.x_ld + (ok ? col : 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float v = xp[(size_t)(2 * j) * a.x_ld];
+            B[slot][j] = ok ? v : 0.f;
+        }
+    };
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < PF; ++i)
+        if (i < ns) load(i, i);
+    for (int s = 0; s < ns; s += PF) {
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            if (s + i < ns) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[i][j], B[i][j], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[i][j], B[i][j], acc1, 0, 0, 0);
+                }
+                if (s + i + PF < ns) load(i, s + i + PF);
+            }
+        }
+    }
+    // accumulator r of a lane: channel 8 (r / 4) + 4 (lane / 32) + r % 4 of its block of 32, frame lane % 32 of the tile
+    auto finish = [&](float v, int cb, int r) {
+        const int co = cb * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
+        if (co >= a.Cout || n >= a.L) return;
+        v = v + a.bias[co];
+        if constexpr (OUT_ACT == OUT_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+        if (a.yt && co >= a.yt_from) {
+            a.yt[z * a.yt_bs + (size_t)n * a.yt_ld + (co - a.yt_from)] = v;
+            return;
+        }
+        const size_t o = z * a.y_bs + (size_t)co * a.y_ld + n;
+        if (a.res) v = v + a.res[o];
+        a.y[o] = v;
+    };
+    if constexpr (KSPLIT == 4) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            part[(w * 32 + r) * 64 + lane] = acc0[r];
+            part[(w * 32 + 16 + r) * 64 + lane] = acc1[r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = w * 8 + i;                          // this wave finishes a quarter of the 32 accumulator rows
+            const float v = ((part[r * 64 + lane] + part[(32 + r) * 64 + lane]) + part[(64 + r) * 64 + lane]) + part[(96 + r) * 64 + lane];
+            if (r < 16) finish(v, cb0, r);
+            else if (live1) finish(v, cb0 + 1, r - 16);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            finish(acc0[r], cb0, r);
+            if (live1) finish(acc1[r], cb0 + 1, r);
+        }
+    }
 }
 
 // The estimator's input (decoder.py:254-260): rows 0..79 x, 80..159 mu, 160..239 the speaker vector on every frame,
@@ -157,11 +348,14 @@ __global__ void pack_input_kernel(const float* __restrict__ x, const float* __re
 // is rounded on its own, as the reference's separate tensor operations are.
 __global__ void euler_step_kernel(const float* __restrict__ d, size_t d_bs, float* __restrict__ in, size_t in_bs, int ld, int L, float dt,
                                   float one_plus_rate, float rate, float* __restrict__ mel) {
+#pragma clang fp contract(off)
     const int t = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
     if (t >= L) return;
     const size_t o = (size_t)c * ld + t;
-    const float g = __fsub_rn(__fmul_rn(one_plus_rate, d[o]), __fmul_rn(rate, d[d_bs + o]));
-    const float xn = __fadd_rn(in[o], __fmul_rn(dt, g));
+    const float a = one_plus_rate * d[o], b = rate * d[d_bs + o];      // plain operators: the pragma above binds them
+    const float g = a - b;
+    const float p = dt * g;
+    const float xn = in[o] + p;
     in[o] = xn;
     in[in_bs + o] = xn;
     if (mel) mel[(size_t)c * L + t] = xn;
@@ -198,8 +392,8 @@ struct s3cfm {
     Norm final_norm;
     float *freq = nullptr, *t_w1 = nullptr, *t_b1 = nullptr, *t_w2 = nullptr, *t_b2 = nullptr, *mlp_w = nullptr, *mlp_b = nullptr;
     float *emb = nullptr, *th = nullptr, *temb = nullptr, *tvec = nullptr;
-    float *IN = nullptr, *X = nullptr, *Y = nullptr, *Z = nullptr, *CAT = nullptr, *N = nullptr, *QKV = nullptr, *O = nullptr, *H = nullptr,
-          *S = nullptr, *D = nullptr;
+    float *IN = nullptr, *X = nullptr, *Y = nullptr, *Z = nullptr, *CAT = nullptr, *N = nullptr, *QK = nullptr, *VT = nullptr, *O = nullptr, *H = nullptr,
+          *D = nullptr;
 };
 
 namespace {
@@ -242,18 +436,42 @@ int make_norm(s3cfm* h, Norm* n, const std::string& name) {
     return upload(h, &n->g, g->v.data(), kC) || upload(h, &n->b, b->v.data(), kC);
 }
 
-// y[row][Cout][L] = conv(act(x[row][Cin][L])) (+ res) on both rows; pad = zero frames on the left
-int run_lin(const s3cfm* h, const Lin& l, const float* x, int x_rows, float* y, int y_rows, int L, int pad, int act, const float* res,
-            hipStream_t st) {
-    ConvArgs a{};
-    a.x = x; a.x_bs = (size_t)x_rows * h->ld; a.x_ld = h->ld; a.Tin = L;
+// y[row][Cout][L] = out_act(conv(x[row][Cin][L])) (+ res) on both rows; pad = zero frames on the left.  y must not be x.
+int run_lin(const s3cfm* h, const Lin& l, const float* x, int x_rows, float* y, int y_rows, int L, int pad, int out_act, const float* res,
+            hipStream_t st, float* yt = nullptr, int yt_from = 0) {
+    static const bool use_conv = getenv("S3CFM_CONV") && atoi(getenv("S3CFM_CONV")) == 1;    // the vocoder's kernel, for comparison
+    if (use_conv && out_act == OUT_NONE && !yt) {
+        ConvArgs a{};
+        a.x = x; a.x_bs = (size_t)x_rows * h->ld; a.x_ld = h->ld; a.Tin = L;
+        a.wt = l.wt; a.bias = l.bias;
+        a.y = y; a.y_bs = (size_t)y_rows * h->ld; a.y_ld = h->ld; a.Tout = L;
+        a.res = res;
+        a.Cin = l.Cin; a.Cout = l.Cout; a.CoutPad = (l.Cout + 31) / 32 * 32; a.K = l.K;
+        a.dil = 1; a.pad = pad; a.act = ACT_NONE; a.slope = 0.f;
+        a.out_stride = 1; a.out_off = 0; a.Tq = L;
+        return launch_conv1d(a, kRows, st);
+    }
+    LinArgs a{};
+    a.x = x; a.x_bs = (size_t)x_rows * h->ld; a.x_ld = h->ld;
     a.wt = l.wt; a.bias = l.bias;
-    a.y = y; a.y_bs = (size_t)y_rows * h->ld; a.y_ld = h->ld; a.Tout = L;
+    a.y = y; a.y_bs = (size_t)y_rows * h->ld; a.y_ld = h->ld;
     a.res = res;
-    a.Cin = l.Cin; a.Cout = l.Cout; a.CoutPad = (l.Cout + 31) / 32 * 32; a.K = l.K;
-    a.dil = 1; a.pad = pad; a.act = act; a.slope = 0.f;
-    a.out_stride = 1; a.out_off = 0; a.Tq = L;
-    return launch_conv1d(a, kRows, st);
+    a.yt = yt; a.yt_bs = (size_t)h->ld * kVtLd; a.yt_ld = kVtLd; a.yt_from = yt_from;
+    a.Cin = l.Cin; a.Cout = l.Cout; a.CoutPad = (l.Cout + 31) / 32 * 32; a.K = l.K; a.pad = pad; a.L = L;
+    S3_REQUIRE(a.Cin % 32 == 0 && x != y, "linear layer: input channels must be a multiple of 32 and the output a different tensor");
+    const int mb = (a.CoutPad + 63) / 64;
+    // enough 64 x 128 tiles to give every CU several workgroups: no split of the reduction
+    const bool wide = (long long)mb * ((L + 127) / 128) * kRows >= 1024;
+    const dim3 grid(wide ? (L + 127) / 128 : (L + 31) / 32, mb, kRows);
+    if (wide) {
+        if (out_act == OUT_GELU) hipLaunchKernelGGL((lin_kernel<1, OUT_GELU>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((lin_kernel<1, OUT_NONE>), grid, dim3(256), 0, st, a);
+    } else {
+        if (out_act == OUT_GELU) hipLaunchKernelGGL((lin_kernel<4, OUT_GELU>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((lin_kernel<4, OUT_NONE>), grid, dim3(256), 0, st, a);
+    }
+    S3_HIP_CHECK(hipGetLastError());
+    return 0;
 }
 
 int run_ln(const s3cfm* h, int mode, const float* x, float* y, int L, const Norm& n, const float* add, hipStream_t st) {
@@ -269,31 +487,26 @@ int run_ln(const s3cfm* h, int mode, const float* x, float* y, int L, const Norm
 // CausalResnetBlock1D (decoder.py:64-68, matcha/decoder.py:56-61): x [row][Cin][L] -> Y [row][256][L]; x may be X (the
 // convolution kernel must not write the tensor it reads), so the caller swaps X and Y afterwards
 int run_resnet(s3cfm* h, const Resnet& r, const float* x, int x_rows, const float* tvec, int L, hipStream_t st) {
-    if (run_lin(h, r.conv1, x, x_rows, h->Y, kC, L, 2, ACT_NONE, nullptr, st)) return 1;
+    if (run_lin(h, r.conv1, x, x_rows, h->Y, kC, L, 2, OUT_NONE, nullptr, st)) return 1;
     if (run_ln(h, LN_MISH_ADD, h->Y, h->Y, L, r.n1, tvec, st)) return 1;
-    if (run_lin(h, r.conv2, h->Y, kC, h->Z, kC, L, 2, ACT_NONE, nullptr, st)) return 1;
+    if (run_lin(h, r.conv2, h->Y, kC, h->Z, kC, L, 2, OUT_NONE, nullptr, st)) return 1;
     if (run_ln(h, LN_MISH, h->Z, h->Z, L, r.n2, nullptr, st)) return 1;
-    return run_lin(h, r.res, x, x_rows, h->Y, kC, L, 0, ACT_NONE, h->Z, st);
+    return run_lin(h, r.res, x, x_rows, h->Y, kC, L, 0, OUT_NONE, h->Z, st);
 }
 
 // BasicTransformerBlock.forward (matcha/transformer.py:243-316) on X [row][256][L], in place
 int run_transformer(s3cfm* h, const Transformer& b, int L, hipStream_t st) {
     const int ld = h->ld;
     if (run_ln(h, LN_PLAIN, h->X, h->N, L, b.n1, nullptr, st)) return 1;
-    if (run_lin(h, b.qkv, h->N, kC, h->QKV, 3 * kInner, L, 0, ACT_NONE, nullptr, st)) return 1;
-    const long long head = (long long)kDk * ld, row = 3LL * kInner * ld;
-    BGemm qk{h->QKV, head, 1, ld, h->QKV + (size_t)kInner * ld, head, ld, 1, h->S, (long long)L * L, L, L, L, kDk,
-             kHeads, row, row, (long long)kHeads * L * L};
-    if (launch_bgemm(qk, kRows * kHeads, st)) return 1;
-    hipLaunchKernelGGL(softmax_rows_kernel, dim3(L, kRows * kHeads), dim3(256), 0, st, h->S, L);
+    // q and k channel-major into QK, v frame-major into VT
+    if (run_lin(h, b.qkv, h->N, kC, h->QK, 2 * kInner, L, 0, OUT_NONE, nullptr, st, h->VT, 2 * kInner)) return 1;
+    AttnArgs at{h->QK, h->QK + (size_t)kInner * ld, (size_t)2 * kInner * ld, ld, h->VT, (size_t)ld * kVtLd, h->O, (size_t)kInner * ld, L};
+    hipLaunchKernelGGL(attn_kernel, dim3((L + 31) / 32 * kRows * kHeads), dim3(256), 0, st, at);
     S3_HIP_CHECK(hipGetLastError());
-    BGemm av{h->QKV + (size_t)2 * kInner * ld, head, ld, 1, h->S, (long long)L * L, 1, L, h->O, head, ld, kDk, L, L,
-             kHeads, row, (long long)kHeads * L * L, (long long)kInner * ld};
-    if (launch_bgemm(av, kRows * kHeads, st)) return 1;
-    if (run_lin(h, b.out, h->O, kInner, h->X, kC, L, 0, ACT_NONE, h->X, st)) return 1;
+    if (run_lin(h, b.out, h->O, kInner, h->X, kC, L, 0, OUT_NONE, h->X, st)) return 1;
     if (run_ln(h, LN_PLAIN, h->X, h->N, L, b.n3, nullptr, st)) return 1;
-    if (run_lin(h, b.w1, h->N, kC, h->H, kFf, L, 0, ACT_NONE, nullptr, st)) return 1;
-    return run_lin(h, b.w2, h->H, kFf, h->X, kC, L, 0, ACT_GELU, h->X, st);
+    if (run_lin(h, b.w1, h->N, kC, h->H, kFf, L, 0, OUT_GELU, nullptr, st)) return 1;
+    return run_lin(h, b.w2, h->H, kFf, h->X, kC, L, 0, OUT_NONE, h->X, st);
 }
 
 int copy_rows(const float* src, int src_rows, float* dst, int dst_rows, int ld, int L, hipStream_t st) {
@@ -324,19 +537,19 @@ int run_estimator(s3cfm* h, float t, int L, hipStream_t st) {
         if (s == 0) {
             // the skip connection (decoder.py:278), then the stage's trailing causal convolution
             if (copy_rows(h->X, kC, h->CAT + (size_t)kC * ld, 2 * kC, ld, L, st)) return 1;
-            if (run_lin(h, sg.tail, h->X, kC, h->Y, kC, L, 2, ACT_NONE, nullptr, st)) return 1;
+            if (run_lin(h, sg.tail, h->X, kC, h->Y, kC, L, 2, OUT_NONE, nullptr, st)) return 1;
             std::swap(h->X, h->Y);
         } else if (s == kStages - 2) {
             if (copy_rows(h->X, kC, h->CAT, 2 * kC, ld, L, st)) return 1;        // decoder.py:301
         } else if (s == kStages - 1) {
-            if (run_lin(h, sg.tail, h->X, kC, h->Y, kC, L, 2, ACT_NONE, nullptr, st)) return 1;
+            if (run_lin(h, sg.tail, h->X, kC, h->Y, kC, L, 2, OUT_NONE, nullptr, st)) return 1;
             std::swap(h->X, h->Y);
         }
     }
     // final CausalBlock1D and 1x1 projection (decoder.py:315-316)
-    if (run_lin(h, h->final_conv, h->X, kC, h->Y, kC, L, 2, ACT_NONE, nullptr, st)) return 1;
+    if (run_lin(h, h->final_conv, h->X, kC, h->Y, kC, L, 2, OUT_NONE, nullptr, st)) return 1;
     if (run_ln(h, LN_MISH, h->Y, h->Y, L, h->final_norm, nullptr, st)) return 1;
-    return run_lin(h, h->final_proj, h->Y, kC, h->D, kMel, L, 0, ACT_NONE, nullptr, st);
+    return run_lin(h, h->final_proj, h->Y, kC, h->D, kMel, L, 0, OUT_NONE, nullptr, st);
 }
 
 }  // namespace
@@ -346,7 +559,8 @@ extern "C" int s3cfm_create(int32_t device, int32_t max_frames, s3cfm** out) {
     S3_HIP_CHECK(hipSetDevice(device));
     s3cfm* h = new s3cfm();
     h->device = device; h->max_frames = max_frames;
-    h->ld = (max_frames + 31) / 32 * 32;
+    h->ld = (max_frames + 63) / 64 * 64;
+    if ((h->ld / 64) % 2 == 0) h->ld += 64;
     *out = h;
     return 0;
 }
@@ -424,13 +638,14 @@ extern "C" int s3cfm_finalize(s3cfm* h) {
     const float step = -(float)(std::log(10000.0) / (kIn / 2 - 1));
     for (int i = 0; i < kIn / 2; ++i) freq[i] = std::exp((float)i * step);
     if (upload(h, &h->freq, freq.data(), freq.size())) return 1;
-    const size_t ld = h->ld, F = h->max_frames;
+    const size_t ld = h->ld;
     if (dalloc(h, &h->emb, kIn) || dalloc(h, &h->th, kTime) || dalloc(h, &h->temb, kTime) || dalloc(h, &h->tvec, kStages * kC)) return 1;
     if (dalloc(h, &h->IN, kRows * kIn * ld) || dalloc(h, &h->CAT, kRows * 2 * kC * ld) || dalloc(h, &h->D, kRows * kMel * ld)) return 1;
     for (float** p : {&h->X, &h->Y, &h->Z, &h->N})
         if (dalloc(h, p, kRows * kC * ld)) return 1;
-    if (dalloc(h, &h->QKV, kRows * 3 * kInner * ld) || dalloc(h, &h->O, kRows * kInner * ld) || dalloc(h, &h->H, kRows * kFf * ld)) return 1;
-    if (dalloc(h, &h->S, (size_t)kRows * kHeads * F * F)) return 1;
+    if (dalloc(h, &h->QK, kRows * 2 * kInner * ld) || dalloc(h, &h->VT, kRows * kVtLd * ld) || dalloc(h, &h->O, kRows * kInner * ld) ||
+        dalloc(h, &h->H, kRows * kFf * ld))
+        return 1;
     S3_HIP_CHECK(hipDeviceSynchronize());
     h->raw.clear();
     h->finalized = true;

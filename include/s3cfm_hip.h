@@ -20,7 +20,7 @@ extern "C" {
 #endif
 
 #define S3CFM_MEL 80
-#define S3CFM_MAX_FRAMES 8192
+#define S3CFM_MAX_FRAMES 15000
 
 typedef struct s3cfm s3cfm;
 

@@ -256,36 +256,40 @@ __global__ __launch_bounds__(256) void lin_kernel(LinArgs a) {
 
     f32x4 A0[PF], A1[PF];
     float B[PF][4];
+    bool okb[PF];
+    // Loads are unconditional (a step past the end re-reads the last one, a frame outside [0, L) reads frame 0) and the
+    // zeroing happens when the value is used: a select right after the load would make the wave wait for it at once.
     auto load = [&](int slot, int s) {                         // s: step index of this wave, (tap, g) = divmod(s0 + s, g8)
-        const int sg = s0 + s, tap = sg / g8, g = sg - tap * g8;
+        const int sg = s0 + (s < ns ? s : ns - 1), tap = sg / g8, g = sg - tap * g8;
         A0[slot] = w0[(size_t)sg * 64];
         A1[slot] = w1[(size_t)sg * 64];
         const int col = n + tap - a.pad;
         const bool ok = col >= 0 && col < a.L;
+        okb[slot] = ok && s < ns;
         const float* xp = xb + (size_t)(g * 8) * a.x_ld + (ok ? col : 0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float v = xp[(size_t)(2 * j) * a.x_ld];
-            B[slot][j] = ok ? v : 0.f;
-        }
+        for (int j = 0; j < 4; ++j) B[slot][j] = xp[(size_t)(2 * j) * a.x_ld];
     };
     f32x16 acc0, acc1;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
 #pragma unroll
-    for (int i = 0; i < PF; ++i)
-        if (i < ns) load(i, i);
+    for (int i = 0; i < PF; ++i) {
+        load(i, i);
+        __builtin_amdgcn_sched_barrier(0);                     // in slot order: the loop's first wait then leaves PF - 1 groups in flight
+    }
     for (int s = 0; s < ns; s += PF) {
 #pragma unroll
         for (int i = 0; i < PF; ++i) {
-            if (s + i < ns) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[i][j], B[i][j], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[i][j], B[i][j], acc1, 0, 0, 0);
-                }
-                if (s + i + PF < ns) load(i, s + i + PF);
+            for (int j = 0; j < 4; ++j) {
+                const float bv = okb[i] ? B[i][j] : 0.f;
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[i][j], bv, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[i][j], bv, acc1, 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);                 // keep the refill of this slot here, PF steps ahead of its use
+            load(i, s + i + PF);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     // accumulator r of a lane: channel 8 (r / 4) + 4 (lane / 32) + r % 4 of its block of 32, frame lane % 32 of the tile

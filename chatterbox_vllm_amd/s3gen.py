@@ -1,20 +1,21 @@
-"""Token -> waveform with the stages this package has on the GPU, around a flow-matching decoder supplied by the caller.
+"""Token -> waveform on the GPU.
 
 Mirror of the reference's ``S3Token2Wav.inference`` (src/chatterbox_vllm/models/s3gen/s3gen.py:297-317) for a pre-computed
 reference dict (``ref_dict``, the "prod API" of s3gen.py:176-186, as ``ChatterboxTTS`` passes it, tts.py:489-493):
 
-    speech tokens --FlowEncoder--> mu, spks, cond --decoder (caller's)--> mel --HiFTGenerator--> waveform --trim fade-->
+    speech tokens --FlowEncoder--> mu, spks, cond --CausalConditionalCFM--> mel --HiFTGenerator--> waveform --trim fade-->
 
-``decoder`` is any callable with the reference decoder's call signature (flow.py:268-274):
-``decoder(mu=[1, 80, L], mask=[1, 1, L], spks=[1, 80], cond=[1, 80, L], n_timesteps=int) -> (mel [1, 80, L], _)``.
-With the reference installed that is ``s3gen.flow.decoder``; this package does not contain one (the reference's needs
-libraries that are absent here, so it could not be checked)."""
+``decoder`` may replace the flow-matching stage by any callable with the reference decoder's call signature
+(flow.py:279-285): ``decoder(mu=[1, 80, L], mask=[1, 1, L], spks=[1, 80], cond=[1, 80, L], n_timesteps=int) ->
+(mel [1, 80, L], _)``, e.g. the reference's own ``s3gen.flow.decoder`` where its libraries are installed.  The default is this
+package's ``CausalConditionalCFM`` (cfm_decoder.py), built from the ``decoder.estimator.*`` entries of the flow state dict."""
 from __future__ import annotations
 
 from typing import Callable, Dict, Optional, Tuple
 
 import torch
 
+from .cfm_decoder import CausalConditionalCFM
 from .flow_encoder import FlowEncoder
 from .hift import HiFTGenerator
 
@@ -23,11 +24,12 @@ S3GEN_SR = 24000
 
 class S3Token2Wav:
     def __init__(self, flow_state_dict: Dict[str, torch.Tensor], mel2wav_state_dict: Dict[str, torch.Tensor],
-                 decoder: Callable, max_tokens: int = 1500, device: int = 0):
+                 decoder: Optional[Callable] = None, max_tokens: int = 1500, device: int = 0):
         self.device = torch.device("cuda", device)
         self.encoder = FlowEncoder(flow_state_dict, max_tokens=max_tokens, device=device)
         self.mel2wav = HiFTGenerator(mel2wav_state_dict, max_batch=1, max_frames=2 * max_tokens, device=device)
-        self.decoder = decoder
+        self._own_decoder = decoder is None
+        self.decoder = CausalConditionalCFM(flow_state_dict, max_frames=2 * max_tokens, device=device) if decoder is None else decoder
         # silence the first 20 ms and fade in over the next 20 ms (s3gen.py:247-251)
         n_trim = S3GEN_SR // 50
         fade = torch.zeros(2 * n_trim)
@@ -65,3 +67,5 @@ class S3Token2Wav:
     def shutdown(self) -> None:
         self.encoder.shutdown()
         self.mel2wav.shutdown()
+        if self._own_decoder:
+            self.decoder.shutdown()

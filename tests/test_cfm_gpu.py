@@ -87,3 +87,36 @@ def test_limits(cfm):
     inp = CW.synthetic_inputs(701, 10)
     with pytest.raises(ValueError):
         cfm.solve_euler(inp["noise"], CW.t_span(2), inp["mu"], inp["spks"], inp["cond"])
+
+
+def test_token_to_waveform_chain_with_the_packaged_decoder(sd):
+    """S3Token2Wav with its default decoder: tokens -> mu (FlowEncoder) -> mel (CausalConditionalCFM) -> waveform
+    (HiFTGenerator).  The mel is held to the two restatements chained in fp64 (flow.py:262-291 with finalize=True); the
+    waveform is the vocoder's own for that mel."""
+    from chatterbox_vllm_amd import flow_weights as FW, hift_weights as HW
+    from chatterbox_vllm_amd.s3gen import S3Token2Wav
+    from oracle import cfm_oracle as O, flow_encoder_oracle as FO
+    flow_sd = dict(FW.synthetic_state_dict())
+    flow_sd.update(sd)
+    torch.manual_seed(11)                                    # the decoder draws its fixed noise at construction
+    s3 = S3Token2Wav(flow_sd, HW.synthetic_state_dict(), max_tokens=64)
+    n_prompt, n_new = 14, 30
+    g = torch.Generator().manual_seed(8)
+    ref = {"prompt_token": FW.synthetic_tokens(n_prompt, seed=3).view(1, -1),
+           "prompt_feat": 2.0 * torch.randn(1, 2 * n_prompt, 80, generator=g) - 4.0,
+           "embedding": torch.randn(1, 192, generator=g)}
+    new = FW.synthetic_tokens(n_new, seed=4)
+    mel = s3.flow_inference(new, ref, n_timesteps=10)
+    assert mel.shape == (1, 80, 2 * n_new)
+    w64 = {k: v.double() for k, v in flow_sd.items()}
+    tokens = torch.cat([ref["prompt_token"].view(-1), new])
+    mu = FO.token_to_mu(w64, tokens, dtype=torch.float64).t().unsqueeze(0)
+    spks = FO.speaker_projection(w64, ref["embedding"], dtype=torch.float64).view(1, 80)
+    cond = torch.zeros(1, 80, mu.shape[2], dtype=torch.float64)
+    cond[:, :, :2 * n_prompt] = ref["prompt_feat"].double().transpose(1, 2)
+    want = O.cfm_forward(flow_sd, mu, spks, cond, s3.decoder.rand_noise, dtype=torch.float64)[:, :, 2 * n_prompt:]
+    assert _rel(mel, want) < 1e-4
+    wav, _ = s3.inference(new, ref, seed=3)
+    raw, _ = s3.hift_inference(mel, seed=3)
+    assert wav.shape == (1, 2 * n_new * 480) and torch.equal(wav[0, 960:], raw[0, 960:]) and not wav[0, :480].any()
+    s3.shutdown()

@@ -260,10 +260,9 @@ def vocoder_leg(device, batch=8, frames=500, iters=5):
             prof = json.load(fh)
         h = hashlib.sha256()
         d = os.path.join(ROOT, "chatterbox_vllm_amd", "csrc_s3gen")
-        for name in sorted(os.listdir(d)):
-            if name.endswith((".hip", ".h")):
-                with open(os.path.join(d, name), "rb") as fh:
-                    h.update(fh.read())
+        for name in ("hift_common.h", "hift_engine.hip", "hift_kernels.hip"):     # the vocoder's own sources
+            with open(os.path.join(d, name), "rb") as fh:
+                h.update(fh.read())
         if prof.get("kernel_source_sha16") == h.hexdigest()[:16] and (batch, frames) == (8, 500):
             traffic = prof["bytes_per_call"]
     except (OSError, ValueError, KeyError):
@@ -285,6 +284,52 @@ def vocoder_leg(device, batch=8, frames=500, iters=5):
     dt = time.perf_counter() - t0
     rec["cpu_baseline"] = {"value": round(batch * frames * 0.02 / dt, 2), "unit": "audio s/s", "cores": torch.get_num_threads(),
                            "kind": "port", "sample": f"one decode() of the same {batch} x {frames} frames, torch fp32, {dt:.1f} s"}
+    return rec
+
+
+def flow_decoder_leg(device, frames=1000, n_timesteps=10, iters=3):
+    """The token -> waveform side's middle stage: the flow-matching decoder (mu -> mel, fp32), one utterance of `frames`
+    mel frames (20 s at 1000, prompt included), `n_timesteps` Euler steps of two estimator rows each, inputs resident in
+    HBM.  Its roofline is the fp32 matrix pipe: algorithmic FLOP of the estimator's matrix products
+    (cfm_weights.estimator_flop) over the HIP-event time of the whole solve, so layer norms and launch gaps count against
+    it.  The CPU figure is the restatement (torch fp32) on a 500-frame utterance, once."""
+    from chatterbox_vllm_amd import cfm_weights as CW
+    from chatterbox_vllm_amd.cfm_decoder import CausalConditionalCFM
+    sd = CW.synthetic_state_dict()
+    m = CausalConditionalCFM(sd, max_frames=frames, device=device)
+    dev = f"cuda:{device}"
+    inp = {k: v.to(dev) for k, v in CW.synthetic_inputs(frames, frames // 3).items()}
+    ts = CW.t_span(n_timesteps)
+    m.solve_euler(inp["noise"], ts, inp["mu"], inp["spks"], inp["cond"])
+    torch.cuda.synchronize(device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(iters):
+        m.solve_euler(inp["noise"], ts, inp["mu"], inp["spks"], inp["cond"])
+    e1.record()
+    torch.cuda.synchronize(device)
+    wall = (time.perf_counter() - t0) / iters
+    ev_ms = e0.elapsed_time(e1) / iters
+    m.shutdown()
+    flop = CW.estimator_flop(frames) * n_timesteps
+    achieved = flop / (ev_ms * 1e-3) / 1e12
+    rec = {"workload": f"S3Gen flow-matching decoder, one utterance of {frames} mel frames ({frames * 0.02:.0f} s), {n_timesteps} Euler steps "
+                       "x 2 guidance rows, seeded synthetic weights",
+           "metric": "audio seconds per second", "value": round(frames * 0.02 / wall, 1), "unit": "audio s/s",
+           "ms_per_step": round(wall * 1e3, 3), "dtype": "f32", "parity": "restatement unpinned (oracle/cfm_oracle.py)",
+           "roofline": {"bound": "mfma", "kernel": "lin_kernel + attn_kernel (about 4 800 launches of a solve)", "achieved": round(achieved, 2),
+                        "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                        "traffic": None, "event_ms_per_call": round(ev_ms, 3), "algorithmic_gflop_per_call": round(flop / 1e9, 1)}}
+    from oracle import cfm_oracle as CO
+    small = 500
+    inp_c = CW.synthetic_inputs(small, small // 3)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    t0 = time.perf_counter()
+    CO.solve_euler(sd, inp_c["noise"], ts, inp_c["mu"], inp_c["spks"], inp_c["cond"])
+    dt = time.perf_counter() - t0
+    rec["cpu_baseline"] = {"value": round(small * 0.02 / dt, 2), "unit": "audio s/s", "cores": torch.get_num_threads(), "kind": "port",
+                           "sample": f"one solve of a {small}-frame utterance ({n_timesteps} steps), torch fp32, {dt:.1f} s"}
     return rec
 
 
@@ -561,6 +606,7 @@ def main():
                       "configs[4]: multilingual vocabulary, fr + zh mixed, 64 slots, 4 voices"),
         ]
         result["vocoder"] = vocoder_leg(local_rank)
+        result["flow_decoder"] = flow_decoder_leg(local_rank)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.rehearse:   # the CPU leg is timed on the one-GPU run only
         cb, cpu_ids, sub = cpu_baseline(cfg, sd, job, conds, paired=paired)

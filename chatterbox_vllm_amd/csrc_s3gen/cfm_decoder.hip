@@ -228,8 +228,9 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
 // accumulators sharing their B operand), takes its weights in tile order straight from L2 (one 16-byte load per lane per
 // 8 input channels) and its x operand straight from the channel-major tensor (lanes 0-31 read 32 consecutive frames of
 // one channel, lanes 32-63 of the next: two 128-byte segments per load), PF steps ahead in registers; nothing is staged
-// in LDS.  KSPLIT = 4: the four waves of a workgroup split the reduction over (tap, ci) in contiguous quarters and their
-// partial sums meet in LDS in a fixed order; KSPLIT = 1: the waves take four neighbouring 32-frame tiles instead.
+// in LDS.  KSPLIT = 4 or 8: the waves of a workgroup split the reduction over (tap, ci) in contiguous parts and their
+// partial sums meet in LDS in wave order (8 waves when the launch has under two workgroups per CU otherwise);
+// KSPLIT = 1: four waves take four neighbouring 32-frame tiles instead.
 struct LinArgs {
     const float* x; size_t x_bs; int x_ld;
     const float* wt; const float* bias;      // wt in tile order (ConvArgs::wt)
@@ -241,14 +242,14 @@ struct LinArgs {
 enum { OUT_NONE = 0, OUT_GELU = 1 };
 
 template <int KSPLIT, int OUT_ACT>
-__global__ __launch_bounds__(256) void lin_kernel(LinArgs a) {
+__global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void lin_kernel(LinArgs a) {
     constexpr int PF = 4;
-    __shared__ float part[KSPLIT == 4 ? 4 * 32 * 64 : 1];
+    __shared__ float part[KSPLIT > 1 ? KSPLIT * 32 * 64 : 1];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, half = lane >> 5;
-    const int n = (KSPLIT == 4 ? blockIdx.x * 32 : blockIdx.x * 128 + 32 * w) + (lane & 31);
+    const int n = (KSPLIT > 1 ? blockIdx.x * 32 : blockIdx.x * 128 + 32 * w) + (lane & 31);
     const int cb0 = blockIdx.y * 2, z = blockIdx.z;
     const int g8 = a.Cin / 8, steps = a.K * g8;
-    const int ns = KSPLIT == 4 ? steps / 4 : steps, s0 = KSPLIT == 4 ? w * ns : 0;
+    const int ns = steps / KSPLIT, s0 = KSPLIT > 1 ? w * ns : 0;
     const bool live1 = (cb0 + 1) * 32 < a.CoutPad;
     const f32x4* __restrict__ w0 = reinterpret_cast<const f32x4*>(a.wt) + (size_t)cb0 * steps * 64 + lane;
     const f32x4* __restrict__ w1 = reinterpret_cast<const f32x4*>(a.wt) + (size_t)(live1 ? cb0 + 1 : cb0) * steps * 64 + lane;
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(256) void lin_kernel(LinArgs a) {
         if (a.res) v = v + a.res[o];
         a.y[o] = v;
     };
-    if constexpr (KSPLIT == 4) {
+    if constexpr (KSPLIT > 1) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             part[(w * 32 + r) * 64 + lane] = acc0[r];
@@ -314,9 +315,11 @@ __global__ __launch_bounds__(256) void lin_kernel(LinArgs a) {
         }
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int r = w * 8 + i;                          // this wave finishes a quarter of the 32 accumulator rows
-            const float v = ((part[r * 64 + lane] + part[(32 + r) * 64 + lane]) + part[(64 + r) * 64 + lane]) + part[(96 + r) * 64 + lane];
+        for (int i = 0; i < 32 / KSPLIT; ++i) {
+            const int r = w * (32 / KSPLIT) + i;              // this wave finishes its share of the 32 accumulator rows
+            float v = part[r * 64 + lane];
+#pragma unroll
+            for (int j = 1; j < KSPLIT; ++j) v += part[(j * 32 + r) * 64 + lane];      // in wave order
             if (r < 16) finish(v, cb0, r);
             else if (live1) finish(v, cb0 + 1, r - 16);
         }
@@ -462,12 +465,16 @@ int run_lin(const s3cfm* h, const Lin& l, const float* x, int x_rows, float* y, 
     a.res = res;
     a.yt = yt; a.yt_bs = (size_t)h->ld * kVtLd; a.yt_ld = kVtLd; a.yt_from = yt_from;
     a.Cin = l.Cin; a.Cout = l.Cout; a.CoutPad = (l.Cout + 31) / 32 * 32; a.K = l.K; a.pad = pad; a.L = L;
-    S3_REQUIRE(a.Cin % 32 == 0 && x != y, "linear layer: input channels must be a multiple of 32 and the output a different tensor");
+    S3_REQUIRE(a.Cin % 64 == 0 && x != y, "linear layer: input channels must be a multiple of 64 and the output a different tensor");
     const int mb = (a.CoutPad + 63) / 64;
     // enough 64 x 128 tiles to give every CU several workgroups: no split of the reduction
     const bool wide = (long long)mb * ((L + 127) / 128) * kRows >= 1024;
     const dim3 grid(wide ? (L + 127) / 128 : (L + 31) / 32, mb, kRows);
-    if (wide) {
+    const bool split8 = !wide && (long long)mb * ((L + 31) / 32) * kRows < 512;
+    if (split8) {
+        if (out_act == OUT_GELU) hipLaunchKernelGGL((lin_kernel<8, OUT_GELU>), grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((lin_kernel<8, OUT_NONE>), grid, dim3(512), 0, st, a);
+    } else if (wide) {
         if (out_act == OUT_GELU) hipLaunchKernelGGL((lin_kernel<1, OUT_GELU>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((lin_kernel<1, OUT_NONE>), grid, dim3(256), 0, st, a);
     } else {

@@ -22,7 +22,12 @@ _SIGNATURES = {
     "s3cfm_finalize": ([_P], C.c_int),
     "s3cfm_estimator": ([_P, _P, _P, _P, _P, C.c_float, C.c_int32, _P, _P], C.c_int),
     "s3cfm_solve": ([_P, _P, _P, _P, _P, C.c_int32, C.POINTER(C.c_float), C.c_int32, C.c_double, _P, _P], C.c_int),
+    "s3cfm_op_linear": ([_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, C.c_int32,
+                         C.c_int32, C.POINTER(C.c_float), _P], C.c_int),
+    "s3cfm_op_attention": ([_P, _P, C.c_int32, C.c_int32, _P, C.c_int32, C.POINTER(C.c_float), _P], C.c_int),
 }
+
+VT_LD = 576                  # row stride of the frame-major V tensor (512 channels + padding)
 
 
 def _lib() -> C.CDLL:
@@ -122,3 +127,47 @@ class CausalConditionalCFM:
             self.shutdown()
         except Exception:
             pass
+
+
+def linear_op(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, pad: int = 0, gelu: bool = False, res: Optional[torch.Tensor] = None,
+              v_from: Optional[int] = None, iters: int = 0):
+    """``s3cfm_op_linear`` on x [2, Cin, L] (a CUDA tensor; its row stride is the ld the kernel sees), w [Cout, Cin, K] and
+    bias [Cout] (CPU): returns (y [2, Cout or v_from, L], vt [2, L, 512] or None, average microseconds of `iters` launches)."""
+    lib = _lib()
+    assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.shape[0] == 2 and x.stride(2) == 1
+    Cin, L, ld = x.shape[1], x.shape[2], x.stride(1)
+    assert x.stride(0) == Cin * ld
+    w = w.detach().to("cpu", torch.float32).contiguous()
+    bias = bias.detach().to("cpu", torch.float32).contiguous()
+    Cout, K = w.shape[0], w.shape[2]
+    rows = Cout if v_from is None else v_from
+    y_full = torch.zeros(2, rows, ld, dtype=torch.float32, device=x.device)
+    vt_full = None if v_from is None else torch.zeros(2, ld, VT_LD, dtype=torch.float32, device=x.device)
+    if res is not None:
+        r_full = torch.zeros_like(y_full)
+        r_full[:, :, :L] = res
+    us = C.c_float(0)
+    check(lib, lib.s3cfm_op_linear(_ptr(x), Cin, L, ld, C.c_void_p(w.data_ptr()), C.c_void_p(bias.data_ptr()), Cout, K, pad, int(gelu),
+                                   _ptr(r_full) if res is not None else None, _ptr(y_full), _ptr(vt_full) if vt_full is not None else None,
+                                   v_from or 0, iters, C.byref(us), _stream_ptr(x.device)))
+    return y_full[:, :, :L], (None if vt_full is None else vt_full[:, :L, :512]), us.value
+
+
+def attention_op(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, iters: int = 0):
+    """``s3cfm_op_attention`` on q, k, v [2, 512, L] (channel-major, head h in channels 64 h ..): returns (o [2, 512, L],
+    average microseconds of `iters` launches)."""
+    lib = _lib()
+    L = q.shape[2]
+    ld = (L + 63) // 64 * 64
+    if (ld // 64) % 2 == 0:
+        ld += 64
+    dev = q.device
+    qk = torch.zeros(2, 1024, ld, dtype=torch.float32, device=dev)
+    qk[:, :512, :L] = q
+    qk[:, 512:, :L] = k
+    vt = torch.zeros(2, ld, VT_LD, dtype=torch.float32, device=dev)
+    vt[:, :L, :512] = v.transpose(1, 2)
+    o = torch.zeros(2, 512, ld, dtype=torch.float32, device=dev)
+    us = C.c_float(0)
+    check(lib, lib.s3cfm_op_attention(_ptr(qk), _ptr(vt), L, ld, _ptr(o), iters, C.byref(us), _stream_ptr(dev)))
+    return o[:, :, :L], us.value

@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <functional>
 #include <map>
 #include <vector>
 
@@ -24,6 +25,7 @@ constexpr int kBlocks = 4, kMid = 12, kStages = kMid + 2, kRows = 2;
 // Row strides are odd multiples of 256 bytes: a tile's rows (64 channels of K, 32 frames of V) then spread over the L2
 // channels instead of landing on one or two of them, which strides of 2 or 4 KiB would do.
 constexpr int kVtLd = kInner + 64;
+constexpr float kQScale = 0.125f * 1.44269504088896340736f;     // 1 / sqrt(64) and log2(e): softmax in base 2
 
 // ---- kernels -----------------------------------------------------------------------------------------------------
 
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
     const float* qp = a.q + b * a.qk_bs + (size_t)(h * 64 + half) * a.ld + (qn < a.L ? qn : a.L - 1);
     float Q[32];
 #pragma unroll
-    for (int kk = 0; kk < 32; ++kk) Q[kk] = qp[(size_t)(2 * kk) * a.ld] * 0.125f;
+    for (int kk = 0; kk < 32; ++kk) Q[kk] = qp[(size_t)(2 * kk) * a.ld] * kQScale;
     f32x16 o0, o1;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
@@ -171,25 +173,30 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         load_k(t + 4 < ntiles ? t + 4 : t);                    // the last tile loads itself again: no branch to schedule around
         __builtin_amdgcn_sched_barrier(0);
-        // accumulator r of a lane: key key0 + 8 (r / 4) + 4 (lane / 32) + r % 4, query lane % 32
-        float mx = -INFINITY;
+        // accumulator r of a lane: key key0 + 8 (r / 4) + 4 (lane / 32) + r % 4, query lane % 32; scores are in units of
+        // ln 2 (the factor sits in Q), so the exponentials below are single v_exp_f32 instructions
+        if (key0 + 32 > a.L) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = key0 + 8 * (r >> 2) + 4 * half + (r & 3);
-            if (key >= a.L) s[r] = -INFINITY;
-            mx = fmaxf(mx, s[r]);
+            for (int r = 0; r < 16; ++r)
+                if (key0 + 8 * (r >> 2) + 4 * half + (r & 3) >= a.L) s[r] = -INFINITY;
         }
+        float mx = s[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float m_new = fmaxf(m, mx);                      // finite: every tile holds a key below L
-        const float alpha = expf(m - m_new);
         float ps = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { s[r] = expf(s[r] - m_new); ps += s[r]; }
+        for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(s[r] - m_new); ps += s[r]; }
         ps += __shfl_xor(ps, 32);
-        l = l * alpha + ps;
-        m = m_new;
+        if (__any(m_new != m)) {                               // the running maximum rarely moves after the first tiles
+            const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+            l *= alpha;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+            for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+            m = m_new;
+        }
+        l += ps;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0[r], s[r], o0, 0, 0, 0);
@@ -207,7 +214,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
     const float ms = fmaxf(fmaxf(sm[0][lane], sm[1][lane]), fmaxf(sm[2][lane], sm[3][lane]));
     float f[4], lsum = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { f[i] = expf(sm[i][lane] - ms); lsum += f[i] * sl[i][lane]; }   // a wave without tiles: exp(-inf) = 0
+    for (int i = 0; i < 4; ++i) { f[i] = __builtin_amdgcn_exp2f(sm[i][lane] - ms); lsum += f[i] * sl[i][lane]; }   // a wave without tiles: 2^-inf = 0
     const float inv = 1.0f / lsum;
     if (qn >= a.L) return;
 #pragma unroll
@@ -255,6 +262,23 @@ __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void lin_kernel(LinArgs a)
     const f32x4* __restrict__ w1 = reinterpret_cast<const f32x4*>(a.wt) + (size_t)(live1 ? cb0 + 1 : cb0) * steps * 64 + lane;
     const float* __restrict__ xb = a.x + z * a.x_bs + (size_t)half * a.x_ld;
 
+    // The rows this wave will finish (NG groups of four accumulator rows), their biases and residual values: loaded
+    // first, so that the round trip runs under the main loop instead of after it.
+    constexpr int NG = KSPLIT > 1 ? 8 / KSPLIT : 8;
+    auto rbase = [&](int gi) { return (KSPLIT > 1 ? w * (32 / KSPLIT) : 0) + 4 * gi; };
+    float pbias[NG][4], pres[NG][4];
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
+        const int cb = cb0 + (rbase(gi) >> 4), co0 = cb * 32 + 8 * ((rbase(gi) & 15) >> 2) + 4 * half;
+        const bool in_yt = a.yt && co0 >= a.yt_from;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool ok = co0 + e < a.Cout && n < a.L;
+            pbias[gi][e] = ok ? a.bias[co0 + e] : 0.f;
+            pres[gi][e] = (ok && a.res && !in_yt) ? a.res[z * a.y_bs + (size_t)(co0 + e) * a.y_ld + n] : 0.f;
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
     f32x4 A0[PF], A1[PF];
     float B[PF][4];
     bool okb[PF];
@@ -293,19 +317,25 @@ __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void lin_kernel(LinArgs a)
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    // accumulator r of a lane: channel 8 (r / 4) + 4 (lane / 32) + r % 4 of its block of 32, frame lane % 32 of the tile
-    auto finish = [&](float v, int cb, int r) {
-        const int co = cb * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
-        if (co >= a.Cout || n >= a.L) return;
-        v = v + a.bias[co];
-        if constexpr (OUT_ACT == OUT_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
-        if (a.yt && co >= a.yt_from) {
-            a.yt[z * a.yt_bs + (size_t)n * a.yt_ld + (co - a.yt_from)] = v;
+    // accumulator r of a lane: channel 8 (r / 4) + 4 (lane / 32) + r % 4 of its block of 32, frame lane % 32 of the tile.
+    // Rows are finished four at a time (r % 4 = 0 .. 3: four consecutive channels): one 16-byte store per lane into the
+    // frame-major tensor, four row stores into the channel-major one.
+    auto finish4 = [&](const float* acc4, int gi) {
+        const int cb = cb0 + (rbase(gi) >> 4), co0 = cb * 32 + 8 * ((rbase(gi) & 15) >> 2) + 4 * half;
+        if (co0 >= a.Cout || n >= a.L || (cb != cb0 && !live1)) return;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] = acc4[e] + pbias[gi][e];
+            if constexpr (OUT_ACT == OUT_GELU) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752f));
+        }
+        if (a.yt && co0 >= a.yt_from) {
+            *reinterpret_cast<f32x4*>(a.yt + z * a.yt_bs + (size_t)n * a.yt_ld + (co0 - a.yt_from)) = f32x4{v[0], v[1], v[2], v[3]};
             return;
         }
-        const size_t o = z * a.y_bs + (size_t)co * a.y_ld + n;
-        if (a.res) v = v + a.res[o];
-        a.y[o] = v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (co0 + e < a.Cout) a.y[z * a.y_bs + (size_t)(co0 + e) * a.y_ld + n] = v[e] + pres[gi][e];
     };
     if constexpr (KSPLIT > 1) {
 #pragma unroll
@@ -315,19 +345,24 @@ __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void lin_kernel(LinArgs a)
         }
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 32 / KSPLIT; ++i) {
-            const int r = w * (32 / KSPLIT) + i;              // this wave finishes its share of the 32 accumulator rows
-            float v = part[r * 64 + lane];
+        for (int gi = 0; gi < NG; ++gi) {
+            float v[4];
 #pragma unroll
-            for (int j = 1; j < KSPLIT; ++j) v += part[(j * 32 + r) * 64 + lane];      // in wave order
-            if (r < 16) finish(v, cb0, r);
-            else if (live1) finish(v, cb0 + 1, r - 16);
+            for (int e = 0; e < 4; ++e) {
+                const int r = rbase(gi) + e;
+                v[e] = part[r * 64 + lane];
+#pragma unroll
+                for (int j = 1; j < KSPLIT; ++j) v[e] += part[(j * 32 + r) * 64 + lane];      // in wave order
+            }
+            finish4(v, gi);
         }
     } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            finish(acc0[r], cb0, r);
-            if (live1) finish(acc1[r], cb0 + 1, r);
+        for (int gi = 0; gi < NG; ++gi) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gi < 4 ? acc0[4 * gi + e] : acc1[4 * (gi - 4) + e];
+            finish4(v, gi);
         }
     }
 }
@@ -443,6 +478,33 @@ int make_norm(s3cfm* h, Norm* n, const std::string& name) {
     return upload(h, &n->g, g->v.data(), kC) || upload(h, &n->b, b->v.data(), kC);
 }
 
+int launch_lin(const LinArgs& a, int out_act, hipStream_t st) {
+    S3_REQUIRE(a.Cin % 64 == 0 && a.x != a.y, "linear layer: input channels must be a multiple of 64 and the output a different tensor");
+    const int L = a.L, mb = (a.CoutPad + 63) / 64;
+    // enough 64 x 128 tiles to give every CU several workgroups: no split of the reduction
+    const bool wide = (long long)mb * ((L + 127) / 128) * kRows >= 1024;
+    const dim3 grid(wide ? (L + 127) / 128 : (L + 31) / 32, mb, kRows);
+    const bool split8 = !wide && (long long)mb * ((L + 31) / 32) * kRows < 512;
+    if (split8) {
+        if (out_act == OUT_GELU) hipLaunchKernelGGL((lin_kernel<8, OUT_GELU>), grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((lin_kernel<8, OUT_NONE>), grid, dim3(512), 0, st, a);
+    } else if (wide) {
+        if (out_act == OUT_GELU) hipLaunchKernelGGL((lin_kernel<1, OUT_GELU>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((lin_kernel<1, OUT_NONE>), grid, dim3(256), 0, st, a);
+    } else {
+        if (out_act == OUT_GELU) hipLaunchKernelGGL((lin_kernel<4, OUT_GELU>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((lin_kernel<4, OUT_NONE>), grid, dim3(256), 0, st, a);
+    }
+    S3_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_attn(const AttnArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(attn_kernel, dim3((a.L + 31) / 32 * kRows * kHeads), dim3(256), 0, st, a);
+    S3_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 // y[row][Cout][L] = out_act(conv(x[row][Cin][L])) (+ res) on both rows; pad = zero frames on the left.  y must not be x.
 int run_lin(const s3cfm* h, const Lin& l, const float* x, int x_rows, float* y, int y_rows, int L, int pad, int out_act, const float* res,
             hipStream_t st, float* yt = nullptr, int yt_from = 0) {
@@ -465,24 +527,7 @@ int run_lin(const s3cfm* h, const Lin& l, const float* x, int x_rows, float* y, 
     a.res = res;
     a.yt = yt; a.yt_bs = (size_t)h->ld * kVtLd; a.yt_ld = kVtLd; a.yt_from = yt_from;
     a.Cin = l.Cin; a.Cout = l.Cout; a.CoutPad = (l.Cout + 31) / 32 * 32; a.K = l.K; a.pad = pad; a.L = L;
-    S3_REQUIRE(a.Cin % 64 == 0 && x != y, "linear layer: input channels must be a multiple of 64 and the output a different tensor");
-    const int mb = (a.CoutPad + 63) / 64;
-    // enough 64 x 128 tiles to give every CU several workgroups: no split of the reduction
-    const bool wide = (long long)mb * ((L + 127) / 128) * kRows >= 1024;
-    const dim3 grid(wide ? (L + 127) / 128 : (L + 31) / 32, mb, kRows);
-    const bool split8 = !wide && (long long)mb * ((L + 31) / 32) * kRows < 512;
-    if (split8) {
-        if (out_act == OUT_GELU) hipLaunchKernelGGL((lin_kernel<8, OUT_GELU>), grid, dim3(512), 0, st, a);
-        else hipLaunchKernelGGL((lin_kernel<8, OUT_NONE>), grid, dim3(512), 0, st, a);
-    } else if (wide) {
-        if (out_act == OUT_GELU) hipLaunchKernelGGL((lin_kernel<1, OUT_GELU>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((lin_kernel<1, OUT_NONE>), grid, dim3(256), 0, st, a);
-    } else {
-        if (out_act == OUT_GELU) hipLaunchKernelGGL((lin_kernel<4, OUT_GELU>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((lin_kernel<4, OUT_NONE>), grid, dim3(256), 0, st, a);
-    }
-    S3_HIP_CHECK(hipGetLastError());
-    return 0;
+    return launch_lin(a, out_act, st);
 }
 
 int run_ln(const s3cfm* h, int mode, const float* x, float* y, int L, const Norm& n, const float* add, hipStream_t st) {
@@ -512,8 +557,7 @@ int run_transformer(s3cfm* h, const Transformer& b, int L, hipStream_t st) {
     // q and k channel-major into QK, v frame-major into VT
     if (run_lin(h, b.qkv, h->N, kC, h->QK, 2 * kInner, L, 0, OUT_NONE, nullptr, st, h->VT, 2 * kInner)) return 1;
     AttnArgs at{h->QK, h->QK + (size_t)kInner * ld, (size_t)2 * kInner * ld, ld, h->VT, (size_t)ld * kVtLd, h->O, (size_t)kInner * ld, L};
-    hipLaunchKernelGGL(attn_kernel, dim3((L + 31) / 32 * kRows * kHeads), dim3(256), 0, st, at);
-    S3_HIP_CHECK(hipGetLastError());
+    if (launch_attn(at, st)) return 1;
     if (run_lin(h, b.out, h->O, kInner, h->X, kC, L, 0, OUT_NONE, h->X, st)) return 1;
     if (run_ln(h, LN_PLAIN, h->X, h->N, L, b.n3, nullptr, st)) return 1;
     if (run_lin(h, b.w1, h->N, kC, h->H, kFf, L, 0, OUT_GELU, nullptr, st)) return 1;
@@ -703,4 +747,63 @@ extern "C" int s3cfm_solve(s3cfm* h, const float* mu_dev, const float* spks_dev,
         if (step < n_timesteps) dt = t_span[step + 1] - t;
     }
     return 0;
+}
+
+// ---- single operations, for tests and timing --------------------------------------------------------------------------
+
+namespace {
+struct DevBuf {
+    float* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t n) { S3_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&p), n * sizeof(float))); return 0; }
+};
+int time_launches(int iters, hipStream_t st, float* avg_us, const std::function<int()>& launch) {
+    hipEvent_t e0, e1;
+    S3_HIP_CHECK(hipEventCreate(&e0));
+    S3_HIP_CHECK(hipEventCreate(&e1));
+    int rc = launch();                                           // warm-up, and the result the caller reads
+    S3_HIP_CHECK(hipEventRecord(e0, st));
+    for (int i = 0; i < iters && !rc; ++i) rc = launch();
+    S3_HIP_CHECK(hipEventRecord(e1, st));
+    S3_HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    S3_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    if (avg_us) *avg_us = iters > 0 ? ms * 1e3f / iters : 0.f;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
+}
+}  // namespace
+
+extern "C" int s3cfm_op_linear(const float* x_dev, int32_t Cin, int32_t L, int32_t ld, const float* w_host, const float* bias_host, int32_t Cout,
+                               int32_t K, int32_t pad, int32_t gelu, const float* res_dev, float* y_dev, float* yt_dev, int32_t yt_from,
+                               int32_t iters, float* avg_us, void* stream) {
+    S3_REQUIRE(x_dev && w_host && bias_host && y_dev && Cin >= 64 && Cout >= 1 && K >= 1 && L >= 1 && ld >= L && iters >= 0, "bad arguments");
+    S3_REQUIRE(!yt_dev || (yt_from % 32 == 0 && Cout - yt_from == kInner), "the frame-major part must be the last 512 channels");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const std::vector<float> t = s3_tile_conv_weights(w_host, Cout, Cin, K);
+    DevBuf wt, bias;
+    if (wt.alloc(t.size()) || bias.alloc(Cout)) return 1;
+    S3_HIP_CHECK(hipMemcpy(wt.p, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
+    S3_HIP_CHECK(hipMemcpy(bias.p, bias_host, Cout * sizeof(float), hipMemcpyHostToDevice));
+    LinArgs a{};
+    a.x = x_dev; a.x_bs = (size_t)Cin * ld; a.x_ld = ld;
+    a.wt = wt.p; a.bias = bias.p;
+    a.y = y_dev; a.y_bs = (size_t)(yt_dev ? yt_from : Cout) * ld; a.y_ld = ld;
+    a.res = res_dev;
+    a.yt = yt_dev; a.yt_bs = (size_t)ld * kVtLd; a.yt_ld = kVtLd; a.yt_from = yt_from;
+    a.Cin = Cin; a.Cout = Cout; a.CoutPad = (Cout + 31) / 32 * 32; a.K = K; a.pad = pad; a.L = L;
+    const int rc = time_launches(iters, st, avg_us, [&]() { return launch_lin(a, gelu ? OUT_GELU : OUT_NONE, st); });
+    S3_HIP_CHECK(hipStreamSynchronize(st));
+    return rc;
+}
+
+extern "C" int s3cfm_op_attention(const float* qk_dev, const float* vt_dev, int32_t L, int32_t ld, float* o_dev, int32_t iters, float* avg_us,
+                                  void* stream) {
+    S3_REQUIRE(qk_dev && vt_dev && o_dev && L >= 1 && ld >= L && iters >= 0, "bad arguments");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    AttnArgs at{qk_dev, qk_dev + (size_t)kInner * ld, (size_t)2 * kInner * ld, ld, vt_dev, (size_t)ld * kVtLd, o_dev, (size_t)kInner * ld, L};
+    const int rc = time_launches(iters, st, avg_us, [&]() { return launch_attn(at, st); });
+    S3_HIP_CHECK(hipStreamSynchronize(st));
+    return rc;
 }

@@ -47,6 +47,23 @@ int s3cfm_estimator(s3cfm* h, const float* x_dev, const float* mu_dev, const flo
 int s3cfm_solve(s3cfm* h, const float* mu_dev, const float* spks_dev, const float* cond_dev, const float* noise_dev, int32_t L,
                 const float* t_span, int32_t n_timesteps, double cfg_rate, float* mel_dev, void* stream);
 
+/* Single operations of the estimator, for tests and timing; both run the launch once, then `iters` more times between two
+ * events and report the average in *avg_us (may be NULL).  Tensors hold the two guidance rows: [2][channels][ld] fp32.
+ *
+ * The linear layers and causal convolutions (decoder.py:94-97 `CausalConv1d`, every `nn.Linear` of the transformer blocks):
+ * y[row][co][n] = act(bias[co] + sum_{tap, ci} w[co][ci][tap] x[row][ci][n + tap - pad]) (+ res), w_host [Cout][Cin][K] and
+ * bias_host [Cout] in host memory, act = GELU (erf form) when `gelu` is set.  With yt_dev, channels from yt_from on (the last
+ * 512) go frame-major to yt_dev [2][ld][576] instead, the layout the attention takes V in, and y_dev holds yt_from channels. */
+int s3cfm_op_linear(const float* x_dev, int32_t Cin, int32_t L, int32_t ld, const float* w_host, const float* bias_host, int32_t Cout,
+                    int32_t K, int32_t pad, int32_t gelu, const float* res_dev, float* y_dev, float* yt_dev, int32_t yt_from,
+                    int32_t iters, float* avg_us, void* stream);
+
+/* Self-attention of a transformer block (the diffusers default processor as matcha/transformer.py:267-273 calls it: 8 heads x
+ * 64, softmax(q k^T / 8) v, every frame attends to every frame): qk_dev [2][1024][ld] (q in channels 0..511, k in 512..1023,
+ * head h at 64 h ..), vt_dev [2][ld][576] frame-major (channels 0..511 used) -> o_dev [2][512][ld]. */
+int s3cfm_op_attention(const float* qk_dev, const float* vt_dev, int32_t L, int32_t ld, float* o_dev, int32_t iters, float* avg_us,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

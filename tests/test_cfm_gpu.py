@@ -120,3 +120,58 @@ def test_token_to_waveform_chain_with_the_packaged_decoder(sd):
     raw, _ = s3.hift_inference(mel, seed=3)
     assert wav.shape == (1, 2 * n_new * 480) and torch.equal(wav[0, 960:], raw[0, 960:]) and not wav[0, :480].any()
     s3.shutdown()
+
+
+@pytest.mark.parametrize("Cin,Cout,K,pad,L", [(256, 256, 1, 0, 1000), (320, 256, 3, 2, 77), (1024, 256, 1, 0, 333), (512, 256, 3, 2, 50),
+                                               (256, 1024, 1, 0, 1), (256, 80, 1, 0, 97), (256, 1024, 1, 0, 4200)])
+def test_linear_kernel_against_fp64(Cin, Cout, K, pad, L):
+    """Every shape class the estimator launches: the three workgroup forms (8-way and 4-way split of the reduction, none),
+    causal taps, ragged lengths, 80 output channels, GELU and the residual add."""
+    from chatterbox_vllm_amd.cfm_decoder import linear_op
+    g = torch.Generator().manual_seed(Cin + Cout + K + L)
+    x = torch.randn(2, Cin, L, generator=g)
+    w = torch.randn(Cout, Cin, K, generator=g) / (Cin * K) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    res = torch.randn(2, Cout, L, generator=g)
+    gelu = Cout == 1024
+    want = torch.nn.functional.conv1d(torch.nn.functional.pad(x.double(), (pad, 0)), w.double(), b.double())
+    if gelu:
+        want = torch.nn.functional.gelu(want)
+    want = want + res.double()
+    ld = (L + 63) // 64 * 64 + 64
+    xd = torch.zeros(2, Cin, ld, device="cuda")
+    xd[:, :, L:] = 7.0                                        # columns past L must not be read as data
+    xd[:, :, :L] = x.cuda()
+    y, _, _ = linear_op(xd[:, :, :L], w, b, pad=pad, gelu=gelu, res=res.cuda())
+    assert (y.double().cpu() - want).abs().max().item() < 2e-5
+
+
+def test_qkv_projection_writes_v_frame_major():
+    from chatterbox_vllm_amd.cfm_decoder import linear_op
+    L = 210
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 256, L, generator=g)
+    w = torch.randn(1536, 256, 1, generator=g) / 16
+    want = torch.nn.functional.conv1d(x.double(), w.double())
+    xd = torch.zeros(2, 256, 320, device="cuda")
+    xd[:, :, :L] = x.cuda()
+    y, vt, _ = linear_op(xd[:, :, :L], w, torch.zeros(1536), v_from=1024)
+    assert y.shape == (2, 1024, L) and vt.shape == (2, L, 512)
+    assert (y.double().cpu() - want[:, :1024]).abs().max().item() < 1e-5
+    assert (vt.double().cpu() - want[:, 1024:].transpose(1, 2)).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("L", [1, 31, 32, 100, 129, 1000])
+def test_attention_kernel_against_fp64(L):
+    """softmax(q k^T / 8) v per head against fp64, lengths around the 32-key tile and the four-wave split, with score
+    spreads of tens of units so that the running maximum moves."""
+    from chatterbox_vllm_amd.cfm_decoder import attention_op
+    g = torch.Generator().manual_seed(L)
+    q = 2.0 * torch.randn(2, 512, L, generator=g)
+    k = 2.0 * torch.randn(2, 512, L, generator=g)
+    v = torch.randn(2, 512, L, generator=g)
+    o, _ = attention_op(q.cuda(), k.cuda(), v.cuda())
+    qh, kh, vh = (t.double().view(2, 8, 64, L) for t in (q, k, v))
+    a = torch.softmax(qh.transpose(2, 3) @ kh / 8.0, dim=-1)                     # [2, 8, L, L]
+    want = (vh @ a.transpose(2, 3)).reshape(2, 512, L)
+    assert (o.double().cpu() - want).abs().max().item() < 2e-5

@@ -125,6 +125,10 @@ struct AttnArgs {
     float* o; size_t o_bs;                                    // [row][512][ld]
     int L;
 };
+// QT: 32-query tiles per wave (1 or 2).  With two, every K and V value a wave loads feeds twice the matrix work: these
+// kernels take their operands from L2, whose bandwidth is what bounds them, so the two-tile form is the faster one whenever
+// it still gives every CU a workgroup.
+template <int QT>
 __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
     __shared__ float so[4 * 32 * 64];
     __shared__ float sm[4][64], sl[4][64];
@@ -132,15 +136,24 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
     // workgroup i runs on XCD i % 8: give each XCD two of the sixteen (row, head) pairs, so that the K and V it streams
     // (0.5 KiB per frame and pair) stay in its own L2
     const int pair = (blockIdx.x & 7) * 2 + ((blockIdx.x >> 3) & 1), qt = blockIdx.x >> 4;
-    const int qn = qt * 32 + col, b = pair >> 3, h = pair & 7;
-    const float* qp = a.q + b * a.qk_bs + (size_t)(h * 64 + half) * a.ld + (qn < a.L ? qn : a.L - 1);
-    float Q[32];
+    const int b = pair >> 3, h = pair & 7;
+    float Q[QT][32];
 #pragma unroll
-    for (int kk = 0; kk < 32; ++kk) Q[kk] = qp[(size_t)(2 * kk) * a.ld] * kQScale;
-    f32x16 o0, o1;
+    for (int u = 0; u < QT; ++u) {
+        const int qn = (qt * QT + u) * 32 + col;
+        const float* qp = a.q + b * a.qk_bs + (size_t)(h * 64 + half) * a.ld + (qn < a.L ? qn : a.L - 1);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
-    float m = -INFINITY, l = 0.f;
+        for (int kk = 0; kk < 32; ++kk) Q[u][kk] = qp[(size_t)(2 * kk) * a.ld] * kQScale;
+    }
+    f32x16 o0[QT], o1[QT];
+    float m[QT], l[QT];
+#pragma unroll
+    for (int u = 0; u < QT; ++u) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { o0[u][i] = 0.f; o1[u][i] = 0.f; }
+        m[u] = -INFINITY;
+        l[u] = 0.f;
+    }
     const float* kbase = a.k + b * a.qk_bs + (size_t)(h * 64 + half) * a.ld;
     const float* vbase = a.vt + b * a.vt_bs + h * 64 + col;
     const int ntiles = (a.L + 31) / 32;
@@ -165,66 +178,82 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
             v1[r] = vp[32];
         }
         __builtin_amdgcn_sched_barrier(0);
-        f32x16 s;
+        f32x16 s[QT];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) s[i] = 0.f;
+        for (int u = 0; u < QT; ++u)
 #pragma unroll
-        for (int kk = 0; kk < 32; ++kk) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kr[kk], Q[kk], s, 0, 0, 0);
+            for (int i = 0; i < 16; ++i) s[u][i] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 32; ++kk)
+#pragma unroll
+            for (int u = 0; u < QT; ++u) s[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(kr[kk], Q[u][kk], s[u], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         load_k(t + 4 < ntiles ? t + 4 : t);                    // the last tile loads itself again: no branch to schedule around
         __builtin_amdgcn_sched_barrier(0);
         // accumulator r of a lane: key key0 + 8 (r / 4) + 4 (lane / 32) + r % 4, query lane % 32; scores are in units of
         // ln 2 (the factor sits in Q), so the exponentials below are single v_exp_f32 instructions
-        if (key0 + 32 > a.L) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (key0 + 8 * (r >> 2) + 4 * half + (r & 3) >= a.L) s[r] = -INFINITY;
+        for (int u = 0; u < QT; ++u) {
+            if (key0 + 32 > a.L) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (key0 + 8 * (r >> 2) + 4 * half + (r & 3) >= a.L) s[u][r] = -INFINITY;
+            }
+            float mx = s[u][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[u][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m[u], mx);               // finite: every tile holds a key below L
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[u][r] = __builtin_amdgcn_exp2f(s[u][r] - m_new); ps += s[u][r]; }
+            ps += __shfl_xor(ps, 32);
+            if (__any(m_new != m[u])) {                        // the running maximum rarely moves after the first tiles
+                const float alpha = __builtin_amdgcn_exp2f(m[u] - m_new);
+                l[u] *= alpha;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { o0[u][i] *= alpha; o1[u][i] *= alpha; }
+                m[u] = m_new;
+            }
+            l[u] += ps;
         }
-        float mx = s[0];
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_new = fmaxf(m, mx);                      // finite: every tile holds a key below L
-        float ps = 0.f;
+        for (int r = 0; r < 16; ++r)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(s[r] - m_new); ps += s[r]; }
-        ps += __shfl_xor(ps, 32);
-        if (__any(m_new != m)) {                               // the running maximum rarely moves after the first tiles
-            const float alpha = __builtin_amdgcn_exp2f(m - m_new);
-            l *= alpha;
+            for (int u = 0; u < QT; ++u) {
+                o0[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0[r], s[u][r], o0[u], 0, 0, 0);
+                o1[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1[r], s[u][r], o1[u], 0, 0, 0);
+            }
+    }
+    // merge the four waves' partial results, one query tile at a time through the same 32 KiB
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
-            m = m_new;
-        }
-        l += ps;
+    for (int u = 0; u < QT; ++u) {
+        if (u > 0) __syncthreads();
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0[r], s[r], o0, 0, 0, 0);
-            o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1[r], s[r], o1, 0, 0, 0);
+            so[(w * 32 + r) * 64 + lane] = o0[u][r];
+            so[(w * 32 + 16 + r) * 64 + lane] = o1[u][r];
         }
-    }
+        sm[w][lane] = m[u];
+        sl[w][lane] = l[u];
+        __syncthreads();
+        const float ms = fmaxf(fmaxf(sm[0][lane], sm[1][lane]), fmaxf(sm[2][lane], sm[3][lane]));
+        float f[4], lsum = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        so[(w * 32 + r) * 64 + lane] = o0[r];
-        so[(w * 32 + 16 + r) * 64 + lane] = o1[r];
-    }
-    sm[w][lane] = m;
-    sl[w][lane] = l;
-    __syncthreads();
-    const float ms = fmaxf(fmaxf(sm[0][lane], sm[1][lane]), fmaxf(sm[2][lane], sm[3][lane]));
-    float f[4], lsum = 0.f;
+        for (int i = 0; i < 4; ++i) { f[i] = __builtin_amdgcn_exp2f(sm[i][lane] - ms); lsum += f[i] * sl[i][lane]; }   // a wave without tiles: 2^-inf = 0
+        const float inv = 1.0f / lsum;
+        const int qn = (qt * QT + u) * 32 + col;
+        if (qn < a.L) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { f[i] = __builtin_amdgcn_exp2f(sm[i][lane] - ms); lsum += f[i] * sl[i][lane]; }   // a wave without tiles: 2^-inf = 0
-    const float inv = 1.0f / lsum;
-    if (qn >= a.L) return;
+            for (int i = 0; i < 8; ++i) {
+                const int r = w * 8 + i;                       // this wave finishes a quarter of the 64 output channels
+                float v = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int r = w * 8 + i;                               // this wave finishes a quarter of the 64 output channels
-        float v = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v += so[(j * 32 + r) * 64 + lane] * f[j];
-        const int d = (r >> 4) * 32 + 8 * ((r & 15) >> 2) + 4 * half + (r & 3);
-        a.o[b * a.o_bs + (size_t)(h * 64 + d) * a.ld + qn] = v * inv;
+                for (int j = 0; j < 4; ++j) v += so[(j * 32 + r) * 64 + lane] * f[j];
+                const int d = (r >> 4) * 32 + 8 * ((r & 15) >> 2) + 4 * half + (r & 3);
+                a.o[b * a.o_bs + (size_t)(h * 64 + d) * a.ld + qn] = v * inv;
+            }
+        }
     }
 }
 
@@ -267,15 +296,19 @@ __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void lin_kernel(LinArgs a)
     constexpr int NG = KSPLIT > 1 ? 8 / KSPLIT : 8;
     auto rbase = [&](int gi) { return (KSPLIT > 1 ? w * (32 / KSPLIT) : 0) + 4 * gi; };
     float pbias[NG][4], pres[NG][4];
+    const bool has_res = a.res != nullptr;
+    const float* resp = (has_res ? a.res : a.bias) + (has_res ? z * a.y_bs + (size_t)(n < a.L ? n : a.L - 1) : 0);
+    const size_t res_ld = has_res ? a.y_ld : 0;
 #pragma unroll
     for (int gi = 0; gi < NG; ++gi) {
         const int cb = cb0 + (rbase(gi) >> 4), co0 = cb * 32 + 8 * ((rbase(gi) & 15) >> 2) + 4 * half;
-        const bool in_yt = a.yt && co0 >= a.yt_from;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const bool ok = co0 + e < a.Cout && n < a.L;
-            pbias[gi][e] = ok ? a.bias[co0 + e] : 0.f;
-            pres[gi][e] = (ok && a.res && !in_yt) ? a.res[z * a.y_bs + (size_t)(co0 + e) * a.y_ld + n] : 0.f;
+            // clamped addresses, no select on the loaded value (it would make the wave wait here); rows past Cout and
+            // the frame-major rows are never stored with these values
+            const int co = co0 + e < a.Cout ? co0 + e : a.Cout - 1;
+            pbias[gi][e] = a.bias[co];
+            pres[gi][e] = resp[(has_res && !(a.yt && co >= a.yt_from) ? co : 0) * res_ld];
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -335,7 +368,7 @@ __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void lin_kernel(LinArgs a)
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            if (co0 + e < a.Cout) a.y[z * a.y_bs + (size_t)(co0 + e) * a.y_ld + n] = v[e] + pres[gi][e];
+            if (co0 + e < a.Cout) a.y[z * a.y_bs + (size_t)(co0 + e) * a.y_ld + n] = has_res ? v[e] + pres[gi][e] : v[e];
     };
     if constexpr (KSPLIT > 1) {
 #pragma unroll
@@ -482,7 +515,8 @@ int launch_lin(const LinArgs& a, int out_act, hipStream_t st) {
     S3_REQUIRE(a.Cin % 64 == 0 && a.x != a.y, "linear layer: input channels must be a multiple of 64 and the output a different tensor");
     const int L = a.L, mb = (a.CoutPad + 63) / 64;
     // enough 64 x 128 tiles to give every CU several workgroups: no split of the reduction
-    const bool wide = (long long)mb * ((L + 127) / 128) * kRows >= 1024;
+    static const int wide_min = getenv("S3CFM_WIDE_MIN") ? atoi(getenv("S3CFM_WIDE_MIN")) : 1024;
+    const bool wide = (long long)mb * ((L + 127) / 128) * kRows >= wide_min;
     const dim3 grid(wide ? (L + 127) / 128 : (L + 31) / 32, mb, kRows);
     const bool split8 = !wide && (long long)mb * ((L + 31) / 32) * kRows < 512;
     if (split8) {
@@ -500,7 +534,10 @@ int launch_lin(const LinArgs& a, int out_act, hipStream_t st) {
 }
 
 int launch_attn(const AttnArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(attn_kernel, dim3((a.L + 31) / 32 * kRows * kHeads), dim3(256), 0, st, a);
+    static const int force = getenv("S3CFM_ATTN_QT") ? atoi(getenv("S3CFM_ATTN_QT")) : 0;
+    const int wg2 = (a.L + 63) / 64 * kRows * kHeads;           // workgroups of the two-tile form
+    if (force == 2 || (force == 0 && wg2 >= 224)) hipLaunchKernelGGL(attn_kernel<2>, dim3(wg2), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(attn_kernel<1>, dim3((a.L + 31) / 32 * kRows * kHeads), dim3(256), 0, st, a);
     S3_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -292,7 +292,7 @@ def flow_decoder_leg(device, frames=1000, n_timesteps=10, iters=3):
     mel frames (20 s at 1000, prompt included), `n_timesteps` Euler steps of two estimator rows each, inputs resident in
     HBM.  Its roofline is the fp32 matrix pipe: algorithmic FLOP of the estimator's matrix products
     (cfm_weights.estimator_flop) over the HIP-event time of the whole solve, so layer norms and launch gaps count against
-    it.  The CPU figure is the restatement (torch fp32) on a 500-frame utterance, once."""
+    it.  The CPU figure is the restatement (torch fp32) on the same utterance, once."""
     from chatterbox_vllm_amd import cfm_weights as CW
     from chatterbox_vllm_amd.cfm_decoder import CausalConditionalCFM
     sd = CW.synthetic_state_dict()
@@ -322,7 +322,7 @@ def flow_decoder_leg(device, frames=1000, n_timesteps=10, iters=3):
                         "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
                         "traffic": None, "event_ms_per_call": round(ev_ms, 3), "algorithmic_gflop_per_call": round(flop / 1e9, 1)}}
     from oracle import cfm_oracle as CO
-    small = 500
+    small = frames
     inp_c = CW.synthetic_inputs(small, small // 3)
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     t0 = time.perf_counter()

@@ -29,9 +29,12 @@ constexpr float kQScale = 0.125f * 1.44269504088896340736f;     // 1 / sqrt(64) 
 
 // ---- kernels -----------------------------------------------------------------------------------------------------
 
-__device__ __forceinline__ float mish(float x) {             // x * tanh(softplus(x)), softplus linear above 20 as torch's
-    const float sp = x > 20.0f ? x : log1pf(expf(x));
-    return x * tanhf(sp);
+// Mish, x tanh(softplus(x)), as one exponential and one division: with n = e^x, tanh(ln(1 + n)) = n (n + 2) / (n (n + 2) + 2);
+// no cancellation at either end, and like torch's softplus the identity above 20 (where the ratio is 1 to fp32 anyway)
+__device__ __forceinline__ float mish(float x) {
+    if (x > 20.0f) return x;
+    const float n = expf(x), t = n * (n + 2.0f);
+    return x * (t / (t + 2.0f));
 }
 
 enum { LN_PLAIN = 0, LN_MISH = 1, LN_MISH_ADD = 2 };

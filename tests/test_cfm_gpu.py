@@ -161,7 +161,7 @@ def test_qkv_projection_writes_v_frame_major():
     assert (vt.double().cpu() - want[:, 1024:].transpose(1, 2)).abs().max().item() < 1e-5
 
 
-@pytest.mark.parametrize("L", [1, 31, 32, 100, 129, 1000])
+@pytest.mark.parametrize("L", [1, 31, 32, 100, 129, 1000, 2101])
 def test_attention_kernel_against_fp64(L):
     """softmax(q k^T / 8) v per head against fp64, lengths around the 32-key tile and the four-wave split, with score
     spreads of tens of units so that the running maximum moves."""

@@ -91,7 +91,7 @@ class FlowEncoder:
         """The keyword arguments of the reference's decoder call (flow.py:268-274) with ``finalize=True``:
         mu [1, 80, L], mask [1, 1, L], spks [1, 80], cond [1, 80, L] (the prompt's mel frames, then zeros)."""
         assert token.shape[0] == 1 and prompt_token.shape[0] == 1, "one utterance per call, as the reference asserts"
-        tokens = torch.cat([prompt_token.reshape(-1), token.reshape(-1)])
+        tokens = torch.cat([prompt_token.reshape(-1).to(self.device), token.reshape(-1).to(self.device)])
         mu = self.token_to_mu(tokens)
         L = mu.shape[2]
         mel_len1 = prompt_feat.shape[1]

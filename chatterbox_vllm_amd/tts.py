@@ -125,6 +125,13 @@ class ChatterboxTTS:
         conds = None
         if (ckpt_dir / "conds.pt").is_file():
             conds = torch.load(ckpt_dir / "conds.pt", weights_only=True, map_location="cpu")
+        if kwargs.get("s3gen") is None and (ckpt_dir / "s3gen.safetensors").is_file():
+            # the reference's S3Gen checkpoint (tts.py:146-148): its flow.* and mel2wav.* entries feed the token -> waveform
+            # chain of this package; the reference-audio side of S3Gen (tokenizer, speaker encoder) is not built
+            from .s3gen import S3Token2Wav
+            s3_sd = load_file(str(ckpt_dir / "s3gen.safetensors"))
+            kwargs["s3gen"] = S3Token2Wav({k[len("flow."):]: v for k, v in s3_sd.items() if k.startswith("flow.")},
+                                          {k[len("mel2wav."):]: v for k, v in s3_sd.items() if k.startswith("mel2wav.")})
         cfg = cls.variant_config(variant)
         # the backbone's depth is the checkpoint's (30 for the published ones): a cut-down checkpoint loads as what it is
         depth = 1 + max((int(k.split(".")[2]) for k in sd if k.startswith("tfmr.layers.")), default=-1)
@@ -153,9 +160,16 @@ class ChatterboxTTS:
 
     @classmethod
     def from_synthetic(cls, variant: str = "english", tokenizer: Optional[Callable] = None, seed: int = 1234,
-                       n_layers: Optional[int] = None, **kwargs) -> "ChatterboxTTS":
+                       n_layers: Optional[int] = None, with_s3gen: bool = False, **kwargs) -> "ChatterboxTTS":
         """Seeded random checkpoint of the exact architecture (no network needed): what the
-        benchmark and the tests run on.  Voices are seeded conditioning prefixes."""
+        benchmark and the tests run on.  Voices are seeded conditioning prefixes.  ``with_s3gen`` attaches the token ->
+        waveform chain on seeded weights too, so that ``generate`` returns waveforms as the reference's does."""
+        if with_s3gen and kwargs.get("s3gen") is None:
+            from . import cfm_weights, flow_weights, hift_weights
+            from .s3gen import S3Token2Wav
+            flow_sd = dict(flow_weights.synthetic_state_dict())
+            flow_sd.update(cfm_weights.synthetic_state_dict())
+            kwargs["s3gen"] = S3Token2Wav(flow_sd, hift_weights.synthetic_state_dict(), max_tokens=kwargs.get("max_model_len", 1000) + 256)
         cfg = cls.variant_config(variant)
         if n_layers is not None:
             cfg = T3ModelConfig(n_layers=n_layers, text_vocab=cfg.text_vocab)
@@ -180,16 +194,27 @@ class ChatterboxTTS:
         if wav_fpath is not None and self.ve is None:
             if self._synthetic_voices:
                 voice = sum(wav_fpath.encode()) % 997 + 1          # a stable seeded voice per path
-                return {}, synthetic_cond_emb(voice, self.t3_config.d_model)
+                return self._synthetic_ref(voice), synthetic_cond_emb(voice, self.t3_config.d_model)
             raise NotImplementedError("audio_prompt_path needs the audio front end (voice encoder + S3 tokenizer), "
                                       "which is outside this package; pass cond_emb to generate_with_conds")
         if self.default_conds is None:
-            return {}, synthetic_cond_emb(0, self.t3_config.d_model)
+            return self._synthetic_ref(0), synthetic_cond_emb(0, self.t3_config.d_model)
         t3c = self.default_conds["t3"]
         tokens = torch.atleast_2d(t3c["cond_prompt_speech_tokens"]).long()
         emb = self._speech_emb[tokens[0]] + self._speech_pos_emb[: tokens.shape[1]]       # tts.py:238
         cond = self._encoder().encode(t3c["speaker_emb"].float(), emb, 0.5)
         return self.default_conds.get("gen", {}), cond.to("cpu")
+
+    def _synthetic_ref(self, voice: int) -> Dict[str, Any]:
+        """A seeded vocoder reference (the `gen` half of the reference's Conditionals, s3gen.py:120-170: prompt tokens, their
+        mel frames, x-vector) for a seeded voice; empty when no token -> waveform chain is attached."""
+        if self.s3gen is None:
+            return {}
+        g = torch.Generator().manual_seed(7000 + voice)
+        n = 50                                                     # two seconds of prompt
+        return {"prompt_token": torch.randint(0, 6561, (1, n), generator=g), "prompt_token_len": torch.tensor([n]),
+                "prompt_feat": 2.0 * torch.randn(1, 2 * n, 80, generator=g) - 4.0, "prompt_feat_len": None,
+                "embedding": torch.randn(1, 192, generator=g)}
 
     def update_exaggeration(self, cond_emb: torch.Tensor, exaggeration: float) -> torch.Tensor:
         if exaggeration == 0.5:
@@ -267,3 +292,6 @@ class ChatterboxTTS:
         if self.t3 is not None:
             self.t3.shutdown()
         self.t3 = None
+        if self.s3gen is not None and hasattr(self.s3gen, "shutdown"):
+            self.s3gen.shutdown()
+            self.s3gen = None

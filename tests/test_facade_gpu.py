@@ -130,3 +130,27 @@ def test_from_local_on_a_checkpoint_directory(tmp_path, golden_dir, monkeypatch)
     eng.shutdown()
     assert [w.outputs[0].token_ids for w in want] == [ro.outputs[0].token_ids for ro in ros]
     assert all(torch.equal(o, postprocess_speech_ids(ro.outputs[0].token_ids, ro.prompt)) for o, ro in zip(out, ros))
+
+
+def test_text_to_waveform_with_the_token_to_waveform_chain_attached(text_fx, monkeypatch):
+    """``generate`` with the S3Gen stages attached returns waveforms, as the reference's does (tts.py:489-493): per prompt
+    the waveform is the chain's for exactly the speech tokens the token-only facade returns, 2 mel frames and 960 samples
+    per token, 24 kHz."""
+    monkeypatch.setenv("CHATTERBOX_DETERMINISTIC", "1")
+    monkeypatch.setenv("CHATTERBOX_CFG_SCALE", "0.5")
+    torch.manual_seed(5)                                           # the flow-matching decoder draws its fixed noise once
+    tts = ChatterboxTTS.from_synthetic(tokenizer=_lookup_tokenizer(text_fx["en"]), n_layers=2, max_model_len=400,
+                                       max_batch_size=3, with_s3gen=True)
+    wavs = tts.generate(EXAMPLE_PROMPTS[:2], max_tokens=40, diffusion_steps=4)
+    ref, _ = tts.get_audio_conditionals(None)
+    s3 = tts.s3gen
+    tts.s3gen = None
+    toks = tts.generate(EXAMPLE_PROMPTS[:2], max_tokens=40)
+    assert len(wavs) == 2 and all(t.numel() > 0 for t in toks)
+    for wav, t in zip(wavs, toks):
+        assert wav.dtype == torch.float32 and wav.shape == (1, 960 * t.numel()) and torch.isfinite(wav).all()
+        again, _ = s3.inference(speech_tokens=t.cuda(), ref_dict=ref, n_timesteps=4)
+        assert torch.equal(again.cpu(), wav)
+        assert not wav[0, :480].any() and wav.abs().max() > 0
+    tts.s3gen = s3
+    tts.shutdown()

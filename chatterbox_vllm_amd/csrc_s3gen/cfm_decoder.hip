@@ -114,6 +114,22 @@ __global__ __launch_bounds__(256) void gemv_kernel(const float* __restrict__ W, 
     }
 }
 
+// Operand loads of the two matrix kernels below go through buffer instructions: a wave-uniform descriptor and byte offset in
+// scalar registers plus a 32-bit byte offset per lane, so that no vector arithmetic is spent on 64-bit addresses (with flat
+// global loads the address arithmetic was a third of the loop's vector instructions).  The wave index is taken through
+// readfirstlane so that the compiler knows what depends on it is uniform.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return f32x4{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
+}
+
 // Self-attention of one transformer block, 8 heads x 64, all frames attend to all frames (the diffusers default attention
 // processor: softmax(q k^T / 8) v).  One workgroup per (32 queries, head, row); its four waves take every fourth 32-key tile
 // and run an online softmax each, and their partial (max, sum, output) triples are merged through LDS in wave order.
@@ -135,7 +151,7 @@ template <int QT>
 __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
     __shared__ float so[4 * 32 * 64];
     __shared__ float sm[4][64], sl[4][64];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, half = lane >> 5, col = lane & 31;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), half = lane >> 5, col = lane & 31;
     // workgroup i runs on XCD i % 8: give each XCD two of the sixteen (row, head) pairs, so that the K and V it streams
     // (0.5 KiB per frame and pair) stay in its own L2
     const int pair = (blockIdx.x & 7) * 2 + ((blockIdx.x >> 3) & 1), qt = blockIdx.x >> 4;
@@ -157,28 +173,29 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
         m[u] = -INFINITY;
         l[u] = 0.f;
     }
-    const float* kbase = a.k + b * a.qk_bs + (size_t)(h * 64 + half) * a.ld;
-    const float* vbase = a.vt + b * a.vt_bs + h * 64 + col;
+    // K of this (row, head): 64 channel rows of ld frames; V: ld frames of kVtLd floats.  Reads past L stay inside the
+    // row stride, which the workspace zero-fills at set-up (the values are masked or multiplied by zero, but must be finite).
+    const __amdgpu_buffer_rsrc_t kr_ = make_rsrc(a.k + b * a.qk_bs + (size_t)(h * 64) * a.ld, 64u * a.ld * 4u);
+    const __amdgpu_buffer_rsrc_t vr_ = make_rsrc(a.vt + b * a.vt_bs + h * 64, (unsigned)a.ld * kVtLd * 4u);
+    const unsigned klane = (unsigned)(half * a.ld + col) * 4u, vlane = (unsigned)(4 * half * kVtLd + col) * 4u;
+    const unsigned krow2 = (unsigned)a.ld * 8u;                // bytes between channels 2 kk and 2 kk + 2
     const int ntiles = (a.L + 31) / 32;
     // A tile's 32 K loads are issued a whole tile ahead (right after the score products that free their registers), its 32 V
     // loads before the score products; the scheduling barriers keep the compiler from sinking each load next to its use,
     // which would leave one load in flight at a time.
     float kr[32], v0[16], v1[16];
     auto load_k = [&](int t) {
-        const int kc = t * 32 + col;
-        const float* kp = kbase + (kc < a.L ? kc : a.L - 1);
 #pragma unroll
-        for (int kk = 0; kk < 32; ++kk) kr[kk] = kp[(size_t)(2 * kk) * a.ld];
+        for (int kk = 0; kk < 32; ++kk) kr[kk] = buf_load(kr_, klane, kk * krow2 + (unsigned)t * 128u);
     };
     if (w < ntiles) load_k(w);
     for (int t = w; t < ntiles; t += 4) {
         const int key0 = t * 32;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int key = key0 + 8 * (r >> 2) + 4 * half + (r & 3);
-            const float* vp = vbase + (size_t)(key < a.L ? key : a.L - 1) * kVtLd;
-            v0[r] = vp[0];
-            v1[r] = vp[32];
+            const unsigned row = (unsigned)(key0 + 8 * (r >> 2) + (r & 3)) * (kVtLd * 4u);
+            v0[r] = buf_load(vr_, vlane, row);
+            v1[r] = buf_load(vr_, vlane + 128u, row);
         }
         __builtin_amdgcn_sched_barrier(0);
         f32x16 s[QT];
@@ -284,15 +301,18 @@ template <int KSPLIT, int OUT_ACT>
 __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void lin_kernel(LinArgs a) {
     constexpr int PF = 4;
     __shared__ float part[KSPLIT > 1 ? KSPLIT * 32 * 64 : 1];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, half = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), half = lane >> 5;
     const int n = (KSPLIT > 1 ? blockIdx.x * 32 : blockIdx.x * 128 + 32 * w) + (lane & 31);
     const int cb0 = blockIdx.y * 2, z = blockIdx.z;
     const int g8 = a.Cin / 8, steps = a.K * g8;
     const int ns = steps / KSPLIT, s0 = KSPLIT > 1 ? w * ns : 0;
     const bool live1 = (cb0 + 1) * 32 < a.CoutPad;
-    const f32x4* __restrict__ w0 = reinterpret_cast<const f32x4*>(a.wt) + (size_t)cb0 * steps * 64 + lane;
-    const f32x4* __restrict__ w1 = reinterpret_cast<const f32x4*>(a.wt) + (size_t)(live1 ? cb0 + 1 : cb0) * steps * 64 + lane;
-    const float* __restrict__ xb = a.x + z * a.x_bs + (size_t)half * a.x_ld;
+    const __amdgpu_buffer_rsrc_t wr_ = make_rsrc(a.wt, (unsigned)(a.CoutPad / 32) * steps * 1024u);
+    const unsigned w0s = (unsigned)cb0 * steps * 1024u;       // this workgroup's first block of 32 channels
+    const __amdgpu_buffer_rsrc_t xr_ = make_rsrc(a.x + z * a.x_bs, (unsigned)a.Cin * a.x_ld * 4u);
+    const unsigned w1d = live1 ? (unsigned)steps * 1024u : 0u;
+    const unsigned wlane = (unsigned)lane * 16u, xlane = (unsigned)(half * a.x_ld + n) * 4u;
+    const unsigned xrow2 = (unsigned)a.x_ld * 8u;              // bytes between channels 2 j and 2 j + 2
 
     // The rows this wave will finish (NG groups of four accumulator rows), their biases and residual values: loaded
     // first, so that the round trip runs under the main loop instead of after it.
@@ -318,18 +338,18 @@ __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void lin_kernel(LinArgs a)
     f32x4 A0[PF], A1[PF];
     float B[PF][4];
     bool okb[PF];
-    // Loads are unconditional (a step past the end re-reads the last one, a frame outside [0, L) reads frame 0) and the
+    // Loads are unconditional (a step past the end re-reads the last one, a frame outside [0, L) reads frame 0 of the row) and the
     // zeroing happens when the value is used: a select right after the load would make the wave wait for it at once.
     auto load = [&](int slot, int s) {                         // s: step index of this wave, (tap, g) = divmod(s0 + s, g8)
         const int sg = s0 + (s < ns ? s : ns - 1), tap = sg / g8, g = sg - tap * g8;
-        A0[slot] = w0[(size_t)sg * 64];
-        A1[slot] = w1[(size_t)sg * 64];
+        A0[slot] = buf_load4(wr_, wlane, w0s + (unsigned)sg * 1024u);
+        A1[slot] = buf_load4(wr_, wlane, w0s + (unsigned)sg * 1024u + w1d);
         const int col = n + tap - a.pad;
         const bool ok = col >= 0 && col < a.L;
         okb[slot] = ok && s < ns;
-        const float* xp = xb + (size_t)(g * 8) * a.x_ld + (ok ? col : 0);
+        const unsigned off = ok ? xlane + (unsigned)((tap - a.pad) * 4) : (unsigned)(half * a.x_ld) * 4u;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) B[slot][j] = xp[(size_t)(2 * j) * a.x_ld];
+        for (int j = 0; j < 4; ++j) B[slot][j] = buf_load(xr_, off, (unsigned)(g * 4 + j) * xrow2);
     };
     f32x16 acc0, acc1;
 #pragma unroll
@@ -741,6 +761,9 @@ extern "C" int s3cfm_finalize(s3cfm* h) {
     if (dalloc(h, &h->QK, kRows * 2 * kInner * ld) || dalloc(h, &h->VT, kRows * kVtLd * ld) || dalloc(h, &h->O, kRows * kInner * ld) ||
         dalloc(h, &h->H, kRows * kFf * ld))
         return 1;
+    // the attention kernel reads K and V up to the end of a 32-frame tile: what lies past an utterance must be finite
+    S3_HIP_CHECK(hipMemset(h->QK, 0, kRows * 2 * kInner * ld * sizeof(float)));
+    S3_HIP_CHECK(hipMemset(h->VT, 0, kRows * kVtLd * ld * sizeof(float)));
     S3_HIP_CHECK(hipDeviceSynchronize());
     h->raw.clear();
     h->finalized = true;
@@ -840,7 +863,7 @@ extern "C" int s3cfm_op_linear(const float* x_dev, int32_t Cin, int32_t L, int32
 
 extern "C" int s3cfm_op_attention(const float* qk_dev, const float* vt_dev, int32_t L, int32_t ld, float* o_dev, int32_t iters, float* avg_us,
                                   void* stream) {
-    S3_REQUIRE(qk_dev && vt_dev && o_dev && L >= 1 && ld >= L && iters >= 0, "bad arguments");
+    S3_REQUIRE(qk_dev && vt_dev && o_dev && L >= 1 && ld >= (L + 31) / 32 * 32 && iters >= 0, "bad arguments (ld must cover whole 32-frame tiles)");
     hipStream_t st = static_cast<hipStream_t>(stream);
     AttnArgs at{qk_dev, qk_dev + (size_t)kInner * ld, (size_t)2 * kInner * ld, ld, vt_dev, (size_t)ld * kVtLd, o_dev, (size_t)kInner * ld, L};
     const int rc = time_launches(iters, st, avg_us, [&]() { return launch_attn(at, st); });

@@ -284,9 +284,9 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
 // accumulators sharing their B operand), takes its weights in tile order straight from L2 (one 16-byte load per lane per
 // 8 input channels) and its x operand straight from the channel-major tensor (lanes 0-31 read 32 consecutive frames of
 // one channel, lanes 32-63 of the next: two 128-byte segments per load), PF steps ahead in registers; nothing is staged
-// in LDS.  KSPLIT = 4 or 8: the waves of a workgroup split the reduction over (tap, ci) in contiguous parts and their
-// partial sums meet in LDS in wave order (8 waves when the launch has under two workgroups per CU otherwise);
-// KSPLIT = 1: four waves take four neighbouring 32-frame tiles instead.
+// in LDS.  KSPLIT = 2, 4 or 8: the waves of a workgroup split the reduction over (tap, ci) in contiguous parts and their
+// partial sums meet in LDS in wave order (8 waves when the launch has under two workgroups per CU; 2 parts x 2 frame tiles
+// when it has plenty); KSPLIT = 1: four waves take four neighbouring 32-frame tiles instead.
 struct LinArgs {
     const float* x; size_t x_bs; int x_ld;
     const float* wt; const float* bias;      // wt in tile order (ConvArgs::wt)
@@ -300,12 +300,14 @@ enum { OUT_NONE = 0, OUT_GELU = 1 };
 template <int KSPLIT, int OUT_ACT>
 __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void lin_kernel(LinArgs a) {
     constexpr int PF = 4;
-    __shared__ float part[KSPLIT > 1 ? KSPLIT * 32 * 64 : 1];
+    __shared__ float part[KSPLIT > 1 ? (KSPLIT == 8 ? 8 : 4) * 32 * 64 : 1];
+    constexpr int NTW = KSPLIT == 8 ? 1 : 4 / KSPLIT;          // waves of a workgroup along the frames
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), half = lane >> 5;
-    const int n = (KSPLIT > 1 ? blockIdx.x * 32 : blockIdx.x * 128 + 32 * w) + (lane & 31);
+    const int kpart = w % KSPLIT, ntile = w / KSPLIT;          // which part of the reduction, which 32-frame tile
+    const int n = (blockIdx.x * NTW + ntile) * 32 + (lane & 31);
     const int cb0 = blockIdx.y * 2, z = blockIdx.z;
     const int g8 = a.Cin / 8, steps = a.K * g8;
-    const int ns = steps / KSPLIT, s0 = KSPLIT > 1 ? w * ns : 0;
+    const int ns = steps / KSPLIT, s0 = kpart * ns;
     const bool live1 = (cb0 + 1) * 32 < a.CoutPad;
     const __amdgpu_buffer_rsrc_t wr_ = make_rsrc(a.wt, (unsigned)(a.CoutPad / 32) * steps * 1024u);
     const unsigned w0s = (unsigned)cb0 * steps * 1024u;       // this workgroup's first block of 32 channels
@@ -317,7 +319,7 @@ __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void lin_kernel(LinArgs a)
     // The rows this wave will finish (NG groups of four accumulator rows), their biases and residual values: loaded
     // first, so that the round trip runs under the main loop instead of after it.
     constexpr int NG = KSPLIT > 1 ? 8 / KSPLIT : 8;
-    auto rbase = [&](int gi) { return (KSPLIT > 1 ? w * (32 / KSPLIT) : 0) + 4 * gi; };
+    auto rbase = [&](int gi) { return kpart * (32 / KSPLIT) + 4 * gi; };
     float pbias[NG][4], pres[NG][4];
     const bool has_res = a.res != nullptr;
     const float* resp = (has_res ? a.res : a.bias) + (has_res ? z * a.y_bs + (size_t)(n < a.L ? n : a.L - 1) : 0);
@@ -406,9 +408,9 @@ __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void lin_kernel(LinArgs a)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int r = rbase(gi) + e;
-                v[e] = part[r * 64 + lane];
+                v[e] = part[(ntile * KSPLIT * 32 + r) * 64 + lane];
 #pragma unroll
-                for (int j = 1; j < KSPLIT; ++j) v[e] += part[(j * 32 + r) * 64 + lane];      // in wave order
+                for (int j = 1; j < KSPLIT; ++j) v[e] += part[((ntile * KSPLIT + j) * 32 + r) * 64 + lane];      // in wave order
             }
             finish4(v, gi);
         }
@@ -539,19 +541,24 @@ int launch_lin(const LinArgs& a, int out_act, hipStream_t st) {
     const int L = a.L, mb = (a.CoutPad + 63) / 64;
     // enough 64 x 128 tiles to give every CU several workgroups: no split of the reduction
     static const int wide_min = getenv("S3CFM_WIDE_MIN") ? atoi(getenv("S3CFM_WIDE_MIN")) : 1024;
-    const bool wide = (long long)mb * ((L + 127) / 128) * kRows >= wide_min;
-    const dim3 grid(wide ? (L + 127) / 128 : (L + 31) / 32, mb, kRows);
-    const bool split8 = !wide && (long long)mb * ((L + 31) / 32) * kRows < 512;
-    if (split8) {
-        if (out_act == OUT_GELU) hipLaunchKernelGGL((lin_kernel<8, OUT_GELU>), grid, dim3(512), 0, st, a);
-        else hipLaunchKernelGGL((lin_kernel<8, OUT_NONE>), grid, dim3(512), 0, st, a);
-    } else if (wide) {
-        if (out_act == OUT_GELU) hipLaunchKernelGGL((lin_kernel<1, OUT_GELU>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((lin_kernel<1, OUT_NONE>), grid, dim3(256), 0, st, a);
-    } else {
-        if (out_act == OUT_GELU) hipLaunchKernelGGL((lin_kernel<4, OUT_GELU>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((lin_kernel<4, OUT_NONE>), grid, dim3(256), 0, st, a);
-    }
+    static const int force_ks = getenv("S3CFM_KS") ? atoi(getenv("S3CFM_KS")) : 0;
+    int ks = 4;
+    if ((long long)mb * ((L + 127) / 128) * kRows >= wide_min) ks = 1;
+    else if ((long long)mb * ((L + 31) / 32) * kRows < 512) ks = 8;
+    else if ((long long)mb * ((L + 63) / 64) * kRows >= 768) ks = 2;      // longer loops per wave once there are three workgroups per CU anyway
+    if (force_ks > 0 && !(ks == 8 && force_ks < 4)) ks = force_ks;
+    const int ntw = ks == 8 ? 1 : 4 / ks;
+    const dim3 grid((L + 32 * ntw - 1) / (32 * ntw), mb, kRows), block(ks == 8 ? 512 : 256);
+#define S3_LIN_LAUNCH(KS)                                                                               \
+    do {                                                                                                \
+        if (out_act == OUT_GELU) hipLaunchKernelGGL((lin_kernel<KS, OUT_GELU>), grid, block, 0, st, a); \
+        else hipLaunchKernelGGL((lin_kernel<KS, OUT_NONE>), grid, block, 0, st, a);                     \
+    } while (0)
+    if (ks == 8) S3_LIN_LAUNCH(8);
+    else if (ks == 4) S3_LIN_LAUNCH(4);
+    else if (ks == 2) S3_LIN_LAUNCH(2);
+    else S3_LIN_LAUNCH(1);
+#undef S3_LIN_LAUNCH
     S3_HIP_CHECK(hipGetLastError());
     return 0;
 }

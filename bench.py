@@ -333,6 +333,46 @@ def flow_decoder_leg(device, frames=1000, n_timesteps=10, iters=3):
     return rec
 
 
+def token_to_waveform_leg(device, prompt_tokens=250, new_tokens=250, iters=3):
+    """The whole token -> waveform chain as the reference's ``S3Token2Wav.inference`` runs it per utterance
+    (s3gen.py:296-317): `prompt_tokens` of voice reference (10 s) + `new_tokens` speech tokens (10 s of new audio) ->
+    flow encoder -> flow-matching decoder (10 steps) -> vocoder -> trim fade, seeded synthetic weights, one utterance at a
+    time.  `value` counts the generated audio only (the prompt's frames are computed and dropped, as in the reference)."""
+    from chatterbox_vllm_amd import cfm_weights as CW, flow_weights as FW, hift_weights as HW
+    from chatterbox_vllm_amd.s3gen import S3Token2Wav
+    flow_sd = dict(FW.synthetic_state_dict())
+    flow_sd.update(CW.synthetic_state_dict())
+    s3 = S3Token2Wav(flow_sd, HW.synthetic_state_dict(), max_tokens=prompt_tokens + new_tokens, device=device)
+    g = torch.Generator().manual_seed(12)
+    ref = {"prompt_token": FW.synthetic_tokens(prompt_tokens, seed=3).view(1, -1),
+           "prompt_feat": (2.0 * torch.randn(1, 2 * prompt_tokens, 80, generator=g) - 4.0).to(f"cuda:{device}"),
+           "embedding": torch.randn(1, 192, generator=g).to(f"cuda:{device}")}
+    new = FW.synthetic_tokens(new_tokens, seed=4).to(f"cuda:{device}")
+    wav, _ = s3.inference(new, ref)
+    torch.cuda.synchronize(device)
+    stage = {}
+    for name, fn in (("flow_encoder", lambda: s3.encoder.decoder_inputs(new.view(1, -1), ref["prompt_token"], ref["prompt_feat"], ref["embedding"])),
+                     ("flow_decoder_and_encoder", lambda: s3.flow_inference(new, ref)),
+                     ("whole", lambda: s3.inference(new, ref))):
+        fn()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        torch.cuda.synchronize(device)
+        stage[name] = (time.perf_counter() - t0) / iters
+    s3.shutdown()
+    audio_s = new_tokens / 25.0
+    return {"workload": f"S3Gen token -> waveform, one utterance: {prompt_tokens} prompt tokens + {new_tokens} new tokens "
+                        f"({2 * (prompt_tokens + new_tokens)} mel frames through the flow stage, {audio_s:.0f} s of new audio), 10 Euler steps",
+            "metric": "generated audio seconds per second", "value": round(audio_s / stage["whole"], 1), "unit": "audio s/s",
+            "ms_per_step": round(stage["whole"] * 1e3, 2), "dtype": "f32", "finite": bool(torch.isfinite(wav).all()),
+            "stage_ms": {"flow_encoder": round(stage["flow_encoder"] * 1e3, 2),
+                         "flow_decoder": round((stage["flow_decoder_and_encoder"] - stage["flow_encoder"]) * 1e3, 2),
+                         "vocoder_and_trim": round((stage["whole"] - stage["flow_decoder_and_encoder"]) * 1e3, 2)},
+            "parity": "flow decoder restatement unpinned; encoder and vocoder pinned by reference outputs"}
+
+
 def extra_leg(args, device, sd_cache, workload, conc, quantization, repeat, label):
     """One short leg of another BASELINE configuration on this GPU: one warm-up pass, one timed pass, one event-timed
     pass.  Returns the record that goes under "other_configs"."""
@@ -607,6 +647,7 @@ def main():
         ]
         result["vocoder"] = vocoder_leg(local_rank)
         result["flow_decoder"] = flow_decoder_leg(local_rank)
+        result["token_to_waveform"] = token_to_waveform_leg(local_rank)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.rehearse:   # the CPU leg is timed on the one-GPU run only
         cb, cpu_ids, sub = cpu_baseline(cfg, sd, job, conds, paired=paired)

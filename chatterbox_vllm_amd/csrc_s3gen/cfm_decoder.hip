@@ -287,16 +287,6 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
 // in LDS.  KSPLIT = 2, 4 or 8: the waves of a workgroup split the reduction over (tap, ci) in contiguous parts and their
 // partial sums meet in LDS in wave order (8 waves when the launch has under two workgroups per CU; 2 parts x 2 frame tiles
 // when it has plenty); KSPLIT = 1: four waves take four neighbouring 32-frame tiles instead.
-struct LinArgs {
-    const float* x; size_t x_bs; int x_ld;
-    const float* wt; const float* bias;      // wt in tile order (ConvArgs::wt)
-    float* y; size_t y_bs; int y_ld;
-    const float* res;                        // layout of y; may be y itself
-    float* yt; size_t yt_bs; int yt_ld, yt_from;   // yt not null: channels >= yt_from go to yt[z][n][co - yt_from] (frame-major)
-    int Cin, Cout, CoutPad, K, pad, L;
-};
-enum { OUT_NONE = 0, OUT_GELU = 1 };
-
 template <int KSPLIT, int OUT_ACT>
 __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void lin_kernel(LinArgs a) {
     constexpr int PF = 4;
@@ -386,6 +376,8 @@ __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void lin_kernel(LinArgs a)
         for (int e = 0; e < 4; ++e) {
             v[e] = acc4[e] + pbias[gi][e];
             if constexpr (OUT_ACT == OUT_GELU) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752f));
+            else if constexpr (OUT_ACT == OUT_SWISH) v[e] = v[e] * (1.0f / (1.0f + expf(-v[e])));
+            else if constexpr (OUT_ACT == OUT_LRELU) v[e] = v[e] > 0.f ? v[e] : v[e] * 0.01f;
         }
         if (a.yt && co0 >= a.yt_from) {
             *reinterpret_cast<f32x4*>(a.yt + z * a.yt_bs + (size_t)n * a.yt_ld + (co0 - a.yt_from)) = f32x4{v[0], v[1], v[2], v[3]};
@@ -536,23 +528,27 @@ int make_norm(s3cfm* h, Norm* n, const std::string& name) {
     return upload(h, &n->g, g->v.data(), kC) || upload(h, &n->b, b->v.data(), kC);
 }
 
-int launch_lin(const LinArgs& a, int out_act, hipStream_t st) {
+}  // namespace
+
+int launch_lin(const LinArgs& a, int out_act, int rows, hipStream_t st) {
     S3_REQUIRE(a.Cin % 64 == 0 && a.x != a.y, "linear layer: input channels must be a multiple of 64 and the output a different tensor");
     const int L = a.L, mb = (a.CoutPad + 63) / 64;
     // enough 64 x 128 tiles to give every CU several workgroups: no split of the reduction
     static const int wide_min = getenv("S3CFM_WIDE_MIN") ? atoi(getenv("S3CFM_WIDE_MIN")) : 1024;
     static const int force_ks = getenv("S3CFM_KS") ? atoi(getenv("S3CFM_KS")) : 0;
     int ks = 4;
-    if ((long long)mb * ((L + 127) / 128) * kRows >= wide_min) ks = 1;
-    else if ((long long)mb * ((L + 31) / 32) * kRows < 512) ks = 8;
-    else if ((long long)mb * ((L + 63) / 64) * kRows >= 768) ks = 2;      // longer loops per wave once there are three workgroups per CU anyway
+    if ((long long)mb * ((L + 127) / 128) * rows >= wide_min) ks = 1;
+    else if ((long long)mb * ((L + 31) / 32) * rows < 512) ks = 8;
+    else if ((long long)mb * ((L + 63) / 64) * rows >= 768) ks = 2;      // longer loops per wave once there are three workgroups per CU anyway
     if (force_ks > 0 && !(ks == 8 && force_ks < 4)) ks = force_ks;
     const int ntw = ks == 8 ? 1 : 4 / ks;
-    const dim3 grid((L + 32 * ntw - 1) / (32 * ntw), mb, kRows), block(ks == 8 ? 512 : 256);
-#define S3_LIN_LAUNCH(KS)                                                                               \
-    do {                                                                                                \
-        if (out_act == OUT_GELU) hipLaunchKernelGGL((lin_kernel<KS, OUT_GELU>), grid, block, 0, st, a); \
-        else hipLaunchKernelGGL((lin_kernel<KS, OUT_NONE>), grid, block, 0, st, a);                     \
+    const dim3 grid((L + 32 * ntw - 1) / (32 * ntw), mb, rows), block(ks == 8 ? 512 : 256);
+#define S3_LIN_LAUNCH(KS)                                                                                      \
+    do {                                                                                                       \
+        if (out_act == OUT_GELU) hipLaunchKernelGGL((lin_kernel<KS, OUT_GELU>), grid, block, 0, st, a);        \
+        else if (out_act == OUT_SWISH) hipLaunchKernelGGL((lin_kernel<KS, OUT_SWISH>), grid, block, 0, st, a); \
+        else if (out_act == OUT_LRELU) hipLaunchKernelGGL((lin_kernel<KS, OUT_LRELU>), grid, block, 0, st, a); \
+        else hipLaunchKernelGGL((lin_kernel<KS, OUT_NONE>), grid, block, 0, st, a);                            \
     } while (0)
     if (ks == 8) S3_LIN_LAUNCH(8);
     else if (ks == 4) S3_LIN_LAUNCH(4);
@@ -562,6 +558,8 @@ int launch_lin(const LinArgs& a, int out_act, hipStream_t st) {
     S3_HIP_CHECK(hipGetLastError());
     return 0;
 }
+
+namespace {
 
 int launch_attn(const AttnArgs& a, hipStream_t st) {
     static const int force = getenv("S3CFM_ATTN_QT") ? atoi(getenv("S3CFM_ATTN_QT")) : 0;
@@ -594,7 +592,7 @@ int run_lin(const s3cfm* h, const Lin& l, const float* x, int x_rows, float* y, 
     a.res = res;
     a.yt = yt; a.yt_bs = (size_t)h->ld * kVtLd; a.yt_ld = kVtLd; a.yt_from = yt_from;
     a.Cin = l.Cin; a.Cout = l.Cout; a.CoutPad = (l.Cout + 31) / 32 * 32; a.K = l.K; a.pad = pad; a.L = L;
-    return launch_lin(a, out_act, st);
+    return launch_lin(a, out_act, kRows, st);
 }
 
 int run_ln(const s3cfm* h, int mode, const float* x, float* y, int L, const Norm& n, const float* add, hipStream_t st) {
@@ -863,7 +861,7 @@ extern "C" int s3cfm_op_linear(const float* x_dev, int32_t Cin, int32_t L, int32
     a.res = res_dev;
     a.yt = yt_dev; a.yt_bs = (size_t)ld * kVtLd; a.yt_ld = kVtLd; a.yt_from = yt_from;
     a.Cin = Cin; a.Cout = Cout; a.CoutPad = (Cout + 31) / 32 * 32; a.K = K; a.pad = pad; a.L = L;
-    const int rc = time_launches(iters, st, avg_us, [&]() { return launch_lin(a, gelu ? OUT_GELU : OUT_NONE, st); });
+    const int rc = time_launches(iters, st, avg_us, [&]() { return launch_lin(a, gelu ? OUT_GELU : OUT_NONE, kRows, st); });
     S3_HIP_CHECK(hipStreamSynchronize(st));
     return rc;
 }

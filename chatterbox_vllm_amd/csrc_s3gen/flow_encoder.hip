@@ -2,9 +2,10 @@
 //
 // Reference: CausalMaskedDiffWithXvec.inference (src/chatterbox_vllm/models/s3gen/flow.py:228-278) up to encoder_proj,
 // UpsampleConformerEncoder.forward (transformer/upsample_encoder.py:256-299).  Activations are kept channel-major,
-// [channel][position] fp32, the layout of the vocoder's tensors: every Linear is then a one-tap convolution for the matrix
-// kernel of hift_kernels.hip (weights as the A operand, positions as N), the three real convolutions (pre-lookahead k = 4
-// and k = 3, upsampling k = 5) use the same kernel, and residual adds ride in its epilogue.  Attention at these lengths
+// [channel][position] fp32, the layout of the vocoder's tensors: every Linear is then a one-tap convolution for the
+// small-tile matrix kernel of cfm_decoder.hip (lin_kernel: weights as the A operand, positions as N), the three real
+// convolutions (pre-lookahead k = 4 and k = 3, upsampling k = 5) use the same kernel, and residual adds and the Swish /
+// leaky ReLU that follow a layer ride in its epilogue.  Attention at these lengths
 // (a few hundred to a few thousand positions, 8 heads x 64) is three small batched matrix products around a softmax:
 //     S_ac[h][i][j] = (q_i + u_h) . k_j        S_bd[h][i][m] = (q_i + v_h) . p_m        (p = linear_pos(pos_emb), 2T - 1 rows)
 //     a[h][i][:]    = softmax_j((S_ac[h][i][j] + S_bd[h][i][T - 1 - i + j]) / 8)       (the reference's rel_shift as an index)
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(256) void speaker_kernel(const float* __restrict__ 
 // ---- host side ---------------------------------------------------------------------------------------------------
 
 struct Host { std::vector<float> v; std::vector<int64_t> shape; };
-struct Lin { float* wt = nullptr; float* bias = nullptr; int Cin = 0, Cout = 0, K = 1; };   // a convolution for launch_conv1d
+struct Lin { float* wt = nullptr; float* bias = nullptr; int Cin = 0, Cout = 0, K = 1; };   // a convolution for launch_lin
 struct Block {
     Lin qkv;                                   // one projection with 2048 outputs: q + pos_bias_u, q + pos_bias_v, k, v
     Lin pos, out, w1, w2;
@@ -267,18 +268,16 @@ int vec(s3flow_enc* h, float** dst, const std::string& name, int n) {
     return upload(h, dst, t->v.data(), n);
 }
 
-// y[Cout][Tout] = conv(act(x[Cin][Tin])) (+ res), one utterance
-int run_lin(const Lin& l, const float* x, int x_ld, int Tin, float* y, int y_ld, int Tout, int pad, int act, float slope,
-            const float* res, hipStream_t st) {
-    ConvArgs a{};
-    a.x = x; a.x_bs = 0; a.x_ld = x_ld; a.Tin = Tin;
+// y[Cout][L] = out_act(conv(x[Cin][L])) (+ res), one utterance, on the small-tile matrix kernel (hift_common.h: LinArgs);
+// pad = zero positions on the left, the taps beyond them look ahead
+int run_lin(const Lin& l, const float* x, int x_ld, int L, float* y, int y_ld, int pad, int out_act, const float* res, hipStream_t st) {
+    LinArgs a{};
+    a.x = x; a.x_bs = 0; a.x_ld = x_ld;
     a.wt = l.wt; a.bias = l.bias;
-    a.y = y; a.y_bs = 0; a.y_ld = y_ld; a.Tout = Tout;
+    a.y = y; a.y_bs = 0; a.y_ld = y_ld;
     a.res = res;
-    a.Cin = l.Cin; a.Cout = l.Cout; a.CoutPad = (l.Cout + 31) / 32 * 32; a.K = l.K;
-    a.dil = 1; a.pad = pad; a.act = act; a.slope = slope;
-    a.out_stride = 1; a.out_off = 0; a.Tq = Tout;
-    return launch_conv1d(a, 1, st);
+    a.Cin = l.Cin; a.Cout = l.Cout; a.CoutPad = (l.Cout + 31) / 32 * 32; a.K = l.K; a.pad = pad; a.L = L;
+    return launch_lin(a, out_act, 1, st);
 }
 
 int run_ln(const float* x, int ldx, float* y, int ldy, int T, const float* g, const float* b, float eps, float scale, hipStream_t st) {
@@ -293,8 +292,8 @@ int run_bgemm(const BGemm& g, int batch, hipStream_t st) { return launch_bgemm(g
 int run_block(s3flow_enc* h, const Block& b, int T, hipStream_t st) {
     const int ld = h->ld, ldp = h->ldp, P2 = 2 * T - 1;
     if (run_ln(h->X, ld, h->N, ld, T, b.g_mha, b.b_mha, 1e-12f, 1.0f, st)) return 1;
-    if (run_lin(b.qkv, h->N, ld, T, h->QU, ld, T, 0, ACT_NONE, 0.f, nullptr, st)) return 1;   // QU, QV, Kb, Vb are one buffer
-    if (run_lin(b.pos, h->PE, ldp, P2, h->P, ldp, P2, 0, ACT_NONE, 0.f, nullptr, st)) return 1;
+    if (run_lin(b.qkv, h->N, ld, T, h->QU, ld, 0, OUT_NONE, nullptr, st)) return 1;   // QU, QV, Kb, Vb are one buffer
+    if (run_lin(b.pos, h->PE, ldp, P2, h->P, ldp, 0, OUT_NONE, nullptr, st)) return 1;
     const long long head = (long long)kDk * ld, headp = (long long)kDk * ldp;
     BGemm ac{h->QU, head, 1, ld, h->Kb, head, ld, 1, h->Sac, (long long)T * T, T, T, T, kDk};
     if (run_bgemm(ac, kHeads, st)) return 1;
@@ -304,10 +303,10 @@ int run_block(s3flow_enc* h, const Block& b, int T, hipStream_t st) {
     S3_HIP_CHECK(hipGetLastError());
     BGemm av{h->Vb, head, ld, 1, h->Sac, (long long)T * T, 1, T, h->O, head, ld, kDk, T, T};
     if (run_bgemm(av, kHeads, st)) return 1;
-    if (run_lin(b.out, h->O, ld, T, h->X, ld, T, 0, ACT_NONE, 0.f, h->X, st)) return 1;
+    if (run_lin(b.out, h->O, ld, T, h->X, ld, 0, OUT_NONE, h->X, st)) return 1;
     if (run_ln(h->X, ld, h->N, ld, T, b.g_ff, b.b_ff, 1e-12f, 1.0f, st)) return 1;
-    if (run_lin(b.w1, h->N, ld, T, h->H, ld, T, 0, ACT_NONE, 0.f, nullptr, st)) return 1;
-    return run_lin(b.w2, h->H, ld, T, h->X, ld, T, 0, ACT_SWISH, 0.f, h->X, st);
+    if (run_lin(b.w1, h->N, ld, T, h->H, ld, 0, OUT_SWISH, nullptr, st)) return 1;
+    return run_lin(b.w2, h->H, ld, T, h->X, ld, 0, OUT_NONE, h->X, st);
 }
 
 int run_pos_emb(s3flow_enc* h, int T, hipStream_t st) {
@@ -431,26 +430,26 @@ extern "C" int s3flow_enc_forward(s3flow_enc* h, const int32_t* tokens_dev, int3
     hipLaunchKernelGGL(embed_gather_kernel, dim3((T + 63) / 64, kD / 4), dim3(256), 0, st, tokens_dev, T, h->emb, h->N, ld);
     S3_HIP_CHECK(hipGetLastError());
     // LinearNoSubsampling + positional scaling (subsampling.py:111-113, embedding.py:267-270)
-    if (run_lin(h->embed, h->N, ld, T, h->X, ld, T, 0, ACT_NONE, 0.f, nullptr, st)) return 1;
+    if (run_lin(h->embed, h->N, ld, T, h->X, ld, 0, OUT_NONE, nullptr, st)) return 1;
     if (run_ln(h->X, ld, h->X, ld, T, h->g_embed, h->b_embed, 1e-5f, xscale, st)) return 1;
     if (run_pos_emb(h, T, st)) return 1;
     // PreLookaheadLayer (upsample_encoder.py:82-99): k = 4 looking 3 positions ahead, leaky ReLU, k = 3 looking back, residual
-    if (run_lin(h->pre1, h->X, ld, T, h->N, ld, T, 0, ACT_NONE, 0.f, nullptr, st)) return 1;
-    if (run_lin(h->pre2, h->N, ld, T, h->X, ld, T, 2, ACT_LRELU, 0.01f, h->X, st)) return 1;
+    if (run_lin(h->pre1, h->X, ld, T, h->N, ld, 0, OUT_LRELU, nullptr, st)) return 1;
+    if (run_lin(h->pre2, h->N, ld, T, h->X, ld, 2, OUT_NONE, h->X, st)) return 1;
     for (int i = 0; i < kBlocks; ++i)
         if (run_block(h, h->blocks[i], T, st)) return 1;
     // Upsample1D (upsample_encoder.py:58-63): nearest x2, k = 5 over the 4 previous positions and the current one
     hipLaunchKernelGGL(upsample2_kernel, dim3((T2 + 255) / 256, kD), dim3(256), 0, st, h->X, ld, h->U, ld, T2);
     S3_HIP_CHECK(hipGetLastError());
-    if (run_lin(h->up_conv, h->U, ld, T2, h->N, ld, T2, 4, ACT_NONE, 0.f, nullptr, st)) return 1;
-    if (run_lin(h->up_embed, h->N, ld, T2, h->X, ld, T2, 0, ACT_NONE, 0.f, nullptr, st)) return 1;
+    if (run_lin(h->up_conv, h->U, ld, T2, h->N, ld, 4, OUT_NONE, nullptr, st)) return 1;
+    if (run_lin(h->up_embed, h->N, ld, T2, h->X, ld, 0, OUT_NONE, nullptr, st)) return 1;
     if (run_ln(h->X, ld, h->X, ld, T2, h->g_up, h->b_up, 1e-5f, xscale, st)) return 1;
     if (run_pos_emb(h, T2, st)) return 1;
     for (int i = 0; i < kUpBlocks; ++i)
         if (run_block(h, h->blocks[kBlocks + i], T2, st)) return 1;
     if (run_ln(h->X, ld, h->HID, ld, T2, h->g_after, h->b_after, 1e-5f, 1.0f, st)) return 1;
     h->last_T = T;
-    return run_lin(h->proj, h->HID, ld, T2, mu_dev, T2, T2, 0, ACT_NONE, 0.f, nullptr, st);
+    return run_lin(h->proj, h->HID, ld, T2, mu_dev, T2, 0, OUT_NONE, nullptr, st);
 }
 
 extern "C" int s3flow_enc_speaker(s3flow_enc* h, const float* xvec_dev, float* spk_dev, void* stream) {

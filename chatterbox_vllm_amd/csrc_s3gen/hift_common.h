@@ -72,6 +72,20 @@ struct BGemm {
 };
 int launch_bgemm(const BGemm& g, int batch, hipStream_t st);
 
+// One launch of the small-tile matrix kernel for linear layers and short convolutions (lin_kernel, cfm_decoder.hip):
+// y[z][co][n] = out_act(bias[co] + sum_{tap, ci} W[co][ci][tap] x[z][ci][n + tap - pad]) (+ res[z][co][n]) for z < rows;
+// x outside [0, L) reads as zero, y must not be x, Cin a multiple of 64.
+struct LinArgs {
+    const float* x; size_t x_bs; int x_ld;
+    const float* wt; const float* bias;      // wt in tile order (ConvArgs::wt)
+    float* y; size_t y_bs; int y_ld;
+    const float* res;                        // layout of y; may be y itself
+    float* yt; size_t yt_bs; int yt_ld, yt_from;   // yt not null: channels >= yt_from go to yt[z][n][co - yt_from] (frame-major)
+    int Cin, Cout, CoutPad, K, pad, L;
+};
+enum { OUT_NONE = 0, OUT_GELU = 1, OUT_SWISH = 2, OUT_LRELU = 3 };   // OUT_LRELU: slope 0.01
+int launch_lin(const LinArgs& a, int out_act, int rows, hipStream_t st);
+
 // W[Cout][Cin][K] (row-major) -> the convolution kernel's tile order (ConvArgs::wt), output channels padded to 32
 inline std::vector<float> s3_tile_conv_weights(const float* w, int Cout, int Cin, int K) {
     const int g8 = Cin / 8, nb = (Cout + 31) / 32;

@@ -144,9 +144,9 @@ struct AttnArgs {
     float* o; size_t o_bs;                                    // [row][512][ld]
     int L;
 };
-// QT: 32-query tiles per wave (1 or 2).  With two, every K and V value a wave loads feeds twice the matrix work: these
-// kernels take their operands from L2, whose bandwidth is what bounds them, so the two-tile form is the faster one whenever
-// it still gives every CU a workgroup.
+// QT: 32-query tiles per wave (1 to 3).  With more tiles every K and V value a wave loads feeds more matrix work and the
+// wave has more independent accumulators in flight (QT = 2 runs a tile 25 % faster than QT = 1); the launcher picks the QT
+// whose workgroup count packs best into the CUs (launch_attn).
 template <int QT>
 __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
     __shared__ float so[4 * 32 * 64];
@@ -287,18 +287,20 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
 // in LDS.  KSPLIT = 2, 4 or 8: the waves of a workgroup split the reduction over (tap, ci) in contiguous parts and their
 // partial sums meet in LDS in wave order (8 waves when the launch has under two workgroups per CU; 2 parts x 2 frame tiles
 // when it has plenty); KSPLIT = 1: four waves take four neighbouring 32-frame tiles instead.
-template <int KSPLIT, int OUT_ACT>
+template <int KSPLIT, int MB, int OUT_ACT>
 __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void lin_kernel(LinArgs a) {
     constexpr int PF = 4;
-    __shared__ float part[KSPLIT > 1 ? (KSPLIT == 8 ? 8 : 4) * 32 * 64 : 1];
+    constexpr int RW = 16 * MB;                                // accumulator rows per lane: MB blocks of 32 channels per wave
+    static_assert(MB == 2 || (MB == 1 && KSPLIT <= 4), "one block per wave needs at least four rows per wave to finish");
+    __shared__ float part[KSPLIT > 1 ? (KSPLIT == 8 ? 8 : 4) * RW * 64 : 1];
     constexpr int NTW = KSPLIT == 8 ? 1 : 4 / KSPLIT;          // waves of a workgroup along the frames
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), half = lane >> 5;
     const int kpart = w % KSPLIT, ntile = w / KSPLIT;          // which part of the reduction, which 32-frame tile
     const int n = (blockIdx.x * NTW + ntile) * 32 + (lane & 31);
-    const int cb0 = blockIdx.y * 2, z = blockIdx.z;
+    const int cb0 = blockIdx.y * MB, z = blockIdx.z;
     const int g8 = a.Cin / 8, steps = a.K * g8;
     const int ns = steps / KSPLIT, s0 = kpart * ns;
-    const bool live1 = (cb0 + 1) * 32 < a.CoutPad;
+    const bool live1 = MB == 2 && (cb0 + 1) * 32 < a.CoutPad;
     const __amdgpu_buffer_rsrc_t wr_ = make_rsrc(a.wt, (unsigned)(a.CoutPad / 32) * steps * 1024u);
     const unsigned w0s = (unsigned)cb0 * steps * 1024u;       // this workgroup's first block of 32 channels
     const __amdgpu_buffer_rsrc_t xr_ = make_rsrc(a.x + z * a.x_bs, (unsigned)a.Cin * a.x_ld * 4u);
@@ -308,8 +310,8 @@ __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void lin_kernel(LinArgs a)
 
     // The rows this wave will finish (NG groups of four accumulator rows), their biases and residual values: loaded
     // first, so that the round trip runs under the main loop instead of after it.
-    constexpr int NG = KSPLIT > 1 ? 8 / KSPLIT : 8;
-    auto rbase = [&](int gi) { return kpart * (32 / KSPLIT) + 4 * gi; };
+    constexpr int NG = RW / KSPLIT / 4;
+    auto rbase = [&](int gi) { return kpart * (RW / KSPLIT) + 4 * gi; };
     float pbias[NG][4], pres[NG][4];
     const bool has_res = a.res != nullptr;
     const float* resp = (has_res ? a.res : a.bias) + (has_res ? z * a.y_bs + (size_t)(n < a.L ? n : a.L - 1) : 0);
@@ -335,7 +337,7 @@ __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void lin_kernel(LinArgs a)
     auto load = [&](int slot, int s) {                         // s: step index of this wave, (tap, g) = divmod(s0 + s, g8)
         const int sg = s0 + (s < ns ? s : ns - 1), tap = sg / g8, g = sg - tap * g8;
         A0[slot] = buf_load4(wr_, wlane, w0s + (unsigned)sg * 1024u);
-        A1[slot] = buf_load4(wr_, wlane, w0s + (unsigned)sg * 1024u + w1d);
+        if constexpr (MB == 2) A1[slot] = buf_load4(wr_, wlane, w0s + (unsigned)sg * 1024u + w1d);
         const int col = n + tap - a.pad;
         const bool ok = col >= 0 && col < a.L;
         okb[slot] = ok && s < ns;
@@ -358,7 +360,7 @@ __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void lin_kernel(LinArgs a)
             for (int j = 0; j < 4; ++j) {
                 const float bv = okb[i] ? B[i][j] : 0.f;
                 acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[i][j], bv, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[i][j], bv, acc1, 0, 0, 0);
+                if constexpr (MB == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[i][j], bv, acc1, 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);                 // keep the refill of this slot here, PF steps ahead of its use
             load(i, s + i + PF);
@@ -390,8 +392,8 @@ __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void lin_kernel(LinArgs a)
     if constexpr (KSPLIT > 1) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            part[(w * 32 + r) * 64 + lane] = acc0[r];
-            part[(w * 32 + 16 + r) * 64 + lane] = acc1[r];
+            part[(w * RW + r) * 64 + lane] = acc0[r];
+            if constexpr (MB == 2) part[(w * RW + 16 + r) * 64 + lane] = acc1[r];
         }
         __syncthreads();
 #pragma unroll
@@ -400,9 +402,9 @@ __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void lin_kernel(LinArgs a)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int r = rbase(gi) + e;
-                v[e] = part[(ntile * KSPLIT * 32 + r) * 64 + lane];
+                v[e] = part[(ntile * KSPLIT * RW + r) * 64 + lane];
 #pragma unroll
-                for (int j = 1; j < KSPLIT; ++j) v[e] += part[((ntile * KSPLIT + j) * 32 + r) * 64 + lane];      // in wave order
+                for (int j = 1; j < KSPLIT; ++j) v[e] += part[((ntile * KSPLIT + j) * RW + r) * 64 + lane];      // in wave order
             }
             finish4(v, gi);
         }
@@ -411,7 +413,7 @@ __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void lin_kernel(LinArgs a)
         for (int gi = 0; gi < NG; ++gi) {
             float v[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = gi < 4 ? acc0[4 * gi + e] : acc1[4 * (gi - 4) + e];
+            for (int e = 0; e < 4; ++e) v[e] = gi < 4 ? acc0[4 * gi + e] : acc1[4 * (gi & 3) + e];
             finish4(v, gi);
         }
     }
@@ -541,19 +543,30 @@ int launch_lin(const LinArgs& a, int out_act, int rows, hipStream_t st) {
     else if ((long long)mb * ((L + 31) / 32) * rows < 512) ks = 8;
     else if ((long long)mb * ((L + 63) / 64) * rows >= 768) ks = 2;      // longer loops per wave once there are three workgroups per CU anyway
     if (force_ks > 0 && !(ks == 8 && force_ks < 4)) ks = force_ks;
+    // One block of 32 channels per wave instead of two (twice the workgroups, each half the work) when the launch is small
+    // and its workgroups pack badly into the 256 CUs: 280 workgroups take 2 units of time, 560 half-size ones 1.5.
+    static const int force_mb = getenv("S3CFM_LIN_MB") ? atoi(getenv("S3CFM_LIN_MB")) : 0;
+    int blocks = 2;
+    if (ks == 8) {
+        const long long u2 = (long long)mb * ((L + 31) / 32) * rows, u1 = (long long)(a.CoutPad / 32) * ((L + 31) / 32) * rows;
+        if ((double)((u1 + 255) / 256) * 1.1 < (double)((u2 + 255) / 256) * 2.0) blocks = 1;
+        if (force_mb == 1 || force_mb == 2) blocks = force_mb;
+        if (blocks == 1) ks = 4;
+    }
     const int ntw = ks == 8 ? 1 : 4 / ks;
-    const dim3 grid((L + 32 * ntw - 1) / (32 * ntw), mb, rows), block(ks == 8 ? 512 : 256);
-#define S3_LIN_LAUNCH(KS)                                                                                      \
-    do {                                                                                                       \
-        if (out_act == OUT_GELU) hipLaunchKernelGGL((lin_kernel<KS, OUT_GELU>), grid, block, 0, st, a);        \
-        else if (out_act == OUT_SWISH) hipLaunchKernelGGL((lin_kernel<KS, OUT_SWISH>), grid, block, 0, st, a); \
-        else if (out_act == OUT_LRELU) hipLaunchKernelGGL((lin_kernel<KS, OUT_LRELU>), grid, block, 0, st, a); \
-        else hipLaunchKernelGGL((lin_kernel<KS, OUT_NONE>), grid, block, 0, st, a);                            \
+    const dim3 grid((L + 32 * ntw - 1) / (32 * ntw), blocks == 2 ? mb : a.CoutPad / 32, rows), block(ks == 8 ? 512 : 256);
+#define S3_LIN_LAUNCH(KS, MB)                                                                                      \
+    do {                                                                                                           \
+        if (out_act == OUT_GELU) hipLaunchKernelGGL((lin_kernel<KS, MB, OUT_GELU>), grid, block, 0, st, a);        \
+        else if (out_act == OUT_SWISH) hipLaunchKernelGGL((lin_kernel<KS, MB, OUT_SWISH>), grid, block, 0, st, a); \
+        else if (out_act == OUT_LRELU) hipLaunchKernelGGL((lin_kernel<KS, MB, OUT_LRELU>), grid, block, 0, st, a); \
+        else hipLaunchKernelGGL((lin_kernel<KS, MB, OUT_NONE>), grid, block, 0, st, a);                            \
     } while (0)
-    if (ks == 8) S3_LIN_LAUNCH(8);
-    else if (ks == 4) S3_LIN_LAUNCH(4);
-    else if (ks == 2) S3_LIN_LAUNCH(2);
-    else S3_LIN_LAUNCH(1);
+    if (blocks == 1) S3_LIN_LAUNCH(4, 1);
+    else if (ks == 8) S3_LIN_LAUNCH(8, 2);
+    else if (ks == 4) S3_LIN_LAUNCH(4, 2);
+    else if (ks == 2) S3_LIN_LAUNCH(2, 2);
+    else S3_LIN_LAUNCH(1, 2);
 #undef S3_LIN_LAUNCH
     S3_HIP_CHECK(hipGetLastError());
     return 0;
@@ -563,9 +576,23 @@ namespace {
 
 int launch_attn(const AttnArgs& a, hipStream_t st) {
     static const int force = getenv("S3CFM_ATTN_QT") ? atoi(getenv("S3CFM_ATTN_QT")) : 0;
-    const int wg2 = (a.L + 63) / 64 * kRows * kHeads;           // workgroups of the two-tile form
-    if (force == 2 || (force == 0 && wg2 >= 224)) hipLaunchKernelGGL(attn_kernel<2>, dim3(wg2), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(attn_kernel<1>, dim3((a.L + 31) / 32 * kRows * kHeads), dim3(256), 0, st, a);
+    // Query tiles per wave: a workgroup of QT tiles costs about QT units of time on its CU and a launch takes as long as
+    // its most loaded CU: pick the QT whose number of workgroups packs best into the 256 CUs (1 100 frames: 560 workgroups of
+    // one tile or 192 of three take 3 units, 288 of two take 4).
+    const int tiles = (a.L + 31) / 32;
+    int best = 1;
+    double best_cost = 1e30;
+    for (int qt = 1; qt <= 3; ++qt) {                          // four tiles per wave would spill registers
+        const long long wgs = (long long)((tiles + qt - 1) / qt) * kRows * kHeads;
+        const double per_tile = qt == 1 ? 1.02 : 1.0;           // measured: one tile per wave is a few per cent slower per tile
+        const double cost = (double)((wgs + 255) / 256) * qt * per_tile;
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = qt; }
+    }
+    if (force >= 1 && force <= 3) best = force;
+    const dim3 grid((tiles + best - 1) / best * kRows * kHeads);
+    if (best == 1) hipLaunchKernelGGL(attn_kernel<1>, grid, dim3(256), 0, st, a);
+    else if (best == 2) hipLaunchKernelGGL(attn_kernel<2>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(attn_kernel<3>, grid, dim3(256), 0, st, a);
     S3_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -154,3 +154,33 @@ def test_text_to_waveform_with_the_token_to_waveform_chain_attached(text_fx, mon
         assert not wav[0, :480].any() and wav.abs().max() > 0
     tts.s3gen = s3
     tts.shutdown()
+
+
+def test_from_local_attaches_the_waveform_chain_when_the_directory_holds_s3gen(tmp_path, golden_dir, monkeypatch):
+    """A checkpoint directory that also holds s3gen.safetensors (the file the reference loads into S3Gen, tts.py:146-148) and
+    a conds.pt with the vocoder reference in its `gen` half: from_local builds the token -> waveform chain from the
+    `flow.*` and `mel2wav.*` entries (other entries, like the reference-audio side's, are ignored) and generate() returns
+    24 kHz waveforms, 960 samples per speech token."""
+    from safetensors.torch import save_file
+    from test_host_cpu import _write_checkpoint_dir
+    from chatterbox_vllm_amd import cfm_weights as CW, flow_weights as FW, hift_weights as HW
+    from chatterbox_vllm_amd.s3gen import S3Token2Wav
+    monkeypatch.setenv("CHATTERBOX_DETERMINISTIC", "1")
+    monkeypatch.setenv("CHATTERBOX_CFG_SCALE", "0.5")
+    _write_checkpoint_dir(str(tmp_path), golden_dir, n_layers=2)
+    s3 = {"flow." + k: v for k, v in FW.synthetic_state_dict().items()}
+    s3.update({"flow." + k: v for k, v in CW.synthetic_state_dict().items()})
+    s3.update({"mel2wav." + k: v for k, v in HW.synthetic_state_dict().items()})
+    s3["speaker_encoder.head.weight"] = torch.zeros(4, 4)          # not taken
+    save_file({k: v.contiguous() for k, v in s3.items()}, os.path.join(str(tmp_path), "s3gen.safetensors"))
+    g = torch.Generator().manual_seed(3)
+    conds = torch.load(os.path.join(str(tmp_path), "conds.pt"), weights_only=True)
+    conds["gen"] = {"prompt_token": torch.randint(0, 6561, (1, 40), generator=g), "prompt_token_len": torch.tensor([40]),
+                    "prompt_feat": 2.0 * torch.randn(1, 80, 80, generator=g) - 4.0, "embedding": torch.randn(1, 192, generator=g)}
+    torch.save(conds, os.path.join(str(tmp_path), "conds.pt"))
+    tts = ChatterboxTTS.from_local(str(tmp_path), max_model_len=200, max_batch_size=2)
+    assert isinstance(tts.s3gen, S3Token2Wav)
+    wavs = tts.generate(["Hi there."], max_tokens=20, diffusion_steps=3)
+    n_tok = postprocess_speech_ids(tts.last_request_outputs[0].outputs[0].token_ids, tts.last_request_outputs[0].prompt).numel()
+    assert n_tok > 0 and wavs[0].shape == (1, 960 * n_tok) and torch.isfinite(wavs[0]).all() and wavs[0].abs().max() > 0
+    tts.shutdown()

@@ -3,9 +3,9 @@
 // Reference: CausalConditionalCFM.forward / ConditionalCFM.solve_euler (src/chatterbox_vllm/models/s3gen/flow_matching.py:
 // 203-228, 82-133) around ConditionalDecoder.forward (decoder.py:233-317).  Every Euler step runs the estimator on two rows
 // (conditioned, unconditioned) of the same x.  Activations are channel-major, [row][channel][frame] fp32, the layout of the
-// vocoder's tensors: the causal convolutions and every Linear go through the matrix kernel of hift_kernels.hip (weights as
-// the A operand, frames as N, a Linear being a one-tap convolution) or, by default, through lin_kernel below, a variant of it
-// shaped for the few output tiles of one utterance; residual adds and the GELU of the feed-forward ride in the epilogue.  LayerNorm over the 256 channels of a frame, with the Mish and the
+// vocoder's tensors: the causal convolutions and every Linear go through lin_kernel below (weights as the A operand, frames
+// as N, a Linear being a one-tap convolution), a matrix kernel shaped for the few output tiles of one utterance; residual
+// adds and the GELU of the feed-forward ride in its epilogue.  LayerNorm over the 256 channels of a frame, with the Mish and the
 // time-embedding add that follow it in a resnet block, is one small kernel.  Attention (8 heads x 64) is one launch with an
 // online softmax (attn_kernel).
 #include "hift_common.h"
@@ -600,18 +600,6 @@ int launch_attn(const AttnArgs& a, hipStream_t st) {
 // y[row][Cout][L] = out_act(conv(x[row][Cin][L])) (+ res) on both rows; pad = zero frames on the left.  y must not be x.
 int run_lin(const s3cfm* h, const Lin& l, const float* x, int x_rows, float* y, int y_rows, int L, int pad, int out_act, const float* res,
             hipStream_t st, float* yt = nullptr, int yt_from = 0) {
-    static const bool use_conv = getenv("S3CFM_CONV") && atoi(getenv("S3CFM_CONV")) == 1;    // the vocoder's kernel, for comparison
-    if (use_conv && out_act == OUT_NONE && !yt) {
-        ConvArgs a{};
-        a.x = x; a.x_bs = (size_t)x_rows * h->ld; a.x_ld = h->ld; a.Tin = L;
-        a.wt = l.wt; a.bias = l.bias;
-        a.y = y; a.y_bs = (size_t)y_rows * h->ld; a.y_ld = h->ld; a.Tout = L;
-        a.res = res;
-        a.Cin = l.Cin; a.Cout = l.Cout; a.CoutPad = (l.Cout + 31) / 32 * 32; a.K = l.K;
-        a.dil = 1; a.pad = pad; a.act = ACT_NONE; a.slope = 0.f;
-        a.out_stride = 1; a.out_off = 0; a.Tq = L;
-        return launch_conv1d(a, kRows, st);
-    }
     LinArgs a{};
     a.x = x; a.x_bs = (size_t)x_rows * h->ld; a.x_ld = h->ld;
     a.wt = l.wt; a.bias = l.bias;

@@ -96,9 +96,8 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BGemm g) {
     __shared__ float As[2][16][96], Bs[2][16][96];            // rows 32 banks apart modulo 64
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w & 1, wn = w >> 1;
     const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
-    const long long z1 = g.zdiv ? blockIdx.z / g.zdiv : 0, z0 = g.zdiv ? blockIdx.z % g.zdiv : blockIdx.z;
-    const float* A = g.A + z1 * g.a_bs2 + z0 * g.a_bs;
-    const float* B = g.B + z1 * g.b_bs2 + z0 * g.b_bs;
+    const float* A = g.A + (size_t)blockIdx.z * g.a_bs;
+    const float* B = g.B + (size_t)blockIdx.z * g.b_bs;
     const bool a_m_fast = g.sam == 1, b_n_fast = g.sbn == 1;  // which index consecutive threads walk
     float ra[4], rb[4];
     auto load = [&](int k0) {
@@ -140,7 +139,7 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BGemm g) {
         if (ch + 1 < nchunk) store(buf ^ 1);
         __syncthreads();
     }
-    float* C = g.C + z1 * g.c_bs2 + z0 * g.c_bs;
+    float* C = g.C + (size_t)blockIdx.z * g.c_bs;
     const int n = n0 + wn * 32 + (lane & 31);
     if (n >= g.N) return;
 #pragma unroll

@@ -9,7 +9,7 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-enum { ACT_NONE = 0, ACT_SNAKE = 1, ACT_LRELU = 2, ACT_ELU = 3, ACT_SWISH = 4, ACT_GELU = 5 };
+enum { ACT_NONE = 0, ACT_SNAKE = 1, ACT_LRELU = 2, ACT_ELU = 3, ACT_SWISH = 4 };
 enum { ACC_NONE = 0, ACC_SET = 1, ACC_ADD = 2, ACC_ADD_DIV3 = 3 };
 
 #define CONV_CK 16          // input channels per LDS tile
@@ -61,14 +61,13 @@ int launch_source(const float* f0, int T, double* prefix, const float* phase, co
                   const float* lb, float* s, int B, hipStream_t st);
 int launch_overwrite_head(float* s, int L, const float* cache, int n_cache, int B, hipStream_t st);
 
-// C[z](m, n) = sum_k A[z](m, k) * B[z](k, n) in fp32 on the matrix cores, operands addressed by element strides.  Batch
-// entry z sits at (z / zdiv) * *_bs2 + (z % zdiv) * *_bs of each operand (zdiv = 0: one level, z * *_bs).
+// C[z](m, n) = sum_k A[z](m, k) * B[z](k, n) in fp32 on the matrix cores, operands addressed by element strides; batch entry
+// z sits at z * *_bs of each operand.
 struct BGemm {
     const float* A; long long a_bs, sam, sak;
     const float* B; long long b_bs, sbk, sbn;
     float* C; long long c_bs, ldc;
     int M, N, K;
-    int zdiv; long long a_bs2, b_bs2, c_bs2;
 };
 int launch_bgemm(const BGemm& g, int batch, hipStream_t st);
 

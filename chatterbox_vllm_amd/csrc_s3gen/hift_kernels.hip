@@ -58,7 +58,6 @@ __device__ __forceinline__ float apply_act(float v, float al, float inv, float s
     else if constexpr (ACT == ACT_LRELU) return v > 0.f ? v : v * slope;
     else if constexpr (ACT == ACT_ELU) return v > 0.f ? v : expf(v) - 1.0f;
     else if constexpr (ACT == ACT_SWISH) return v * (1.0f / (1.0f + expf(-v)));
-    else if constexpr (ACT == ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
     else return v;
 }
 
@@ -608,7 +607,6 @@ int launch_conv1d(const ConvArgs& a, int B, hipStream_t st) {
         case ACT_LRELU: S3_CONV_LAUNCH(ACT_LRELU); break;
         case ACT_ELU: S3_CONV_LAUNCH(ACT_ELU); break;
         case ACT_SWISH: S3_CONV_LAUNCH(ACT_SWISH); break;
-        case ACT_GELU: S3_CONV_LAUNCH(ACT_GELU); break;
         default: S3_REQUIRE(false, "conv1d: unknown activation");
     }
 #undef S3_CONV_LAUNCH

@@ -318,7 +318,7 @@ def flow_decoder_leg(device, frames=1000, n_timesteps=10, iters=3):
                        "x 2 guidance rows, seeded synthetic weights",
            "metric": "audio seconds per second", "value": round(frames * 0.02 / wall, 1), "unit": "audio s/s",
            "ms_per_step": round(wall * 1e3, 3), "dtype": "f32", "parity": "restatement unpinned (oracle/cfm_oracle.py)",
-           "roofline": {"bound": "mfma", "kernel": "lin_kernel + attn_kernel (about 4 800 launches of a solve)", "achieved": round(achieved, 2),
+           "roofline": {"bound": "mfma", "kernel": "lin_kernel + attn_kernel (about 3 700 launches of a solve)", "achieved": round(achieved, 2),
                         "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
                         "traffic": None, "event_ms_per_call": round(ev_ms, 3), "algorithmic_gflop_per_call": round(flop / 1e9, 1)}}
     from oracle import cfm_oracle as CO

@@ -23,7 +23,7 @@ _SIGNATURES = {
     "s3cfm_estimator": ([_P, _P, _P, _P, _P, C.c_float, C.c_int32, _P, _P], C.c_int),
     "s3cfm_solve": ([_P, _P, _P, _P, _P, C.c_int32, C.POINTER(C.c_float), C.c_int32, C.c_double, _P, _P], C.c_int),
     "s3cfm_op_linear": ([_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, C.c_int32,
-                         C.c_int32, C.POINTER(C.c_float), _P], C.c_int),
+                         _P, _P, C.c_int32, C.POINTER(C.c_float), _P], C.c_int),
     "s3cfm_op_attention": ([_P, _P, C.c_int32, C.c_int32, _P, C.c_int32, C.POINTER(C.c_float), _P], C.c_int),
 }
 
@@ -130,7 +130,7 @@ class CausalConditionalCFM:
 
 
 def linear_op(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, pad: int = 0, gelu: bool = False, res: Optional[torch.Tensor] = None,
-              v_from: Optional[int] = None, iters: int = 0):
+              v_from: Optional[int] = None, iters: int = 0, ln: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
     """``s3cfm_op_linear`` on x [2, Cin, L] (a CUDA tensor; its row stride is the ld the kernel sees), w [Cout, Cin, K] and
     bias [Cout] (CPU): returns (y [2, Cout or v_from, L], vt [2, L, 512] or None, average microseconds of `iters` launches)."""
     lib = _lib()
@@ -147,9 +147,13 @@ def linear_op(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, pad: int = 0
         r_full = torch.zeros_like(y_full)
         r_full[:, :, :L] = res
     us = C.c_float(0)
+    gamma = beta = None
+    if ln is not None:                                       # (gain, shift) of a LayerNorm over the input channels, folded into the layer
+        gamma, beta = (t.detach().to("cpu", torch.float32).contiguous() for t in ln)
     check(lib, lib.s3cfm_op_linear(_ptr(x), Cin, L, ld, C.c_void_p(w.data_ptr()), C.c_void_p(bias.data_ptr()), Cout, K, pad, int(gelu),
                                    _ptr(r_full) if res is not None else None, _ptr(y_full), _ptr(vt_full) if vt_full is not None else None,
-                                   v_from or 0, iters, C.byref(us), _stream_ptr(x.device)))
+                                   v_from or 0, C.c_void_p(gamma.data_ptr()) if ln is not None else None,
+                                   C.c_void_p(beta.data_ptr()) if ln is not None else None, iters, C.byref(us), _stream_ptr(x.device)))
     return y_full[:, :, :L], (None if vt_full is None else vt_full[:, :L, :512]), us.value
 
 

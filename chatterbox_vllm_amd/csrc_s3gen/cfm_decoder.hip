@@ -287,12 +287,13 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
 // in LDS.  KSPLIT = 2, 4 or 8: the waves of a workgroup split the reduction over (tap, ci) in contiguous parts and their
 // partial sums meet in LDS in wave order (8 waves when the launch has under two workgroups per CU; 2 parts x 2 frame tiles
 // when it has plenty); KSPLIT = 1: four waves take four neighbouring 32-frame tiles instead.
-template <int KSPLIT, int MB, int OUT_ACT>
+template <int KSPLIT, int MB, int OUT_ACT, bool LN_IN>
 __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void lin_kernel(LinArgs a) {
     constexpr int PF = 4;
     constexpr int RW = 16 * MB;                                // accumulator rows per lane: MB blocks of 32 channels per wave
     static_assert(MB == 2 || (MB == 1 && KSPLIT <= 4), "one block per wave needs at least four rows per wave to finish");
     __shared__ float part[KSPLIT > 1 ? (KSPLIT == 8 ? 8 : 4) * RW * 64 : 1];
+    __shared__ float lnst[LN_IN && KSPLIT > 1 ? (KSPLIT == 8 ? 8 : 4) * 2 * 32 : 1];   // per wave and frame: sum, sum of squares
     constexpr int NTW = KSPLIT == 8 ? 1 : 4 / KSPLIT;          // waves of a workgroup along the frames
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), half = lane >> 5;
     const int kpart = w % KSPLIT, ntile = w / KSPLIT;          // which part of the reduction, which 32-frame tile
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void lin_kernel(LinArgs a)
     // first, so that the round trip runs under the main loop instead of after it.
     constexpr int NG = RW / KSPLIT / 4;
     auto rbase = [&](int gi) { return kpart * (RW / KSPLIT) + 4 * gi; };
-    float pbias[NG][4], pres[NG][4];
+    float pbias[NG][4], pres[NG][4], prsum[LN_IN ? NG : 1][4];
     const bool has_res = a.res != nullptr;
     const float* resp = (has_res ? a.res : a.bias) + (has_res ? z * a.y_bs + (size_t)(n < a.L ? n : a.L - 1) : 0);
     const size_t res_ld = has_res ? a.y_ld : 0;
@@ -326,6 +327,7 @@ __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void lin_kernel(LinArgs a)
             const int co = co0 + e < a.Cout ? co0 + e : a.Cout - 1;
             pbias[gi][e] = a.bias[co];
             pres[gi][e] = resp[(has_res && !(a.yt && co >= a.yt_from) ? co : 0) * res_ld];
+            if constexpr (LN_IN) prsum[gi][e] = a.rsum[co];
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -348,6 +350,7 @@ __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void lin_kernel(LinArgs a)
     f32x16 acc0, acc1;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+    float ln_s1 = 0.f, ln_s2 = 0.f;                            // LN_IN: this lane's share of its frame's sum and sum of squares
 #pragma unroll
     for (int i = 0; i < PF; ++i) {
         load(i, i);
@@ -359,6 +362,7 @@ __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void lin_kernel(LinArgs a)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float bv = okb[i] ? B[i][j] : 0.f;
+                if constexpr (LN_IN) { ln_s1 += bv; ln_s2 = fmaf(bv, bv, ln_s2); }
                 acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[i][j], bv, acc0, 0, 0, 0);
                 if constexpr (MB == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[i][j], bv, acc1, 0, 0, 0);
             }
@@ -367,6 +371,7 @@ __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void lin_kernel(LinArgs a)
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    float ln_mean = 0.f, ln_rstd = 0.f;                        // LN_IN: set once the frame's sums are complete
     // accumulator r of a lane: channel 8 (r / 4) + 4 (lane / 32) + r % 4 of its block of 32, frame lane % 32 of the tile.
     // Rows are finished four at a time (r % 4 = 0 .. 3: four consecutive channels): one 16-byte store per lane into the
     // frame-major tensor, four row stores into the channel-major one.
@@ -376,7 +381,8 @@ __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void lin_kernel(LinArgs a)
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            v[e] = acc4[e] + pbias[gi][e];
+            if constexpr (LN_IN) v[e] = ln_rstd * (acc4[e] - ln_mean * prsum[gi][e]) + pbias[gi][e];
+            else v[e] = acc4[e] + pbias[gi][e];
             if constexpr (OUT_ACT == OUT_GELU) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752f));
             else if constexpr (OUT_ACT == OUT_SWISH) v[e] = v[e] * (1.0f / (1.0f + expf(-v[e])));
             else if constexpr (OUT_ACT == OUT_LRELU) v[e] = v[e] > 0.f ? v[e] : v[e] * 0.01f;
@@ -389,13 +395,34 @@ __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void lin_kernel(LinArgs a)
         for (int e = 0; e < 4; ++e)
             if (co0 + e < a.Cout) a.y[z * a.y_bs + (size_t)(co0 + e) * a.y_ld + n] = has_res ? v[e] + pres[gi][e] : v[e];
     };
+    if constexpr (LN_IN) {                                     // the two halves of a wave hold the two channel parities of a frame
+        ln_s1 += __shfl_xor(ln_s1, 32);
+        ln_s2 += __shfl_xor(ln_s2, 32);
+    }
     if constexpr (KSPLIT > 1) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             part[(w * RW + r) * 64 + lane] = acc0[r];
             if constexpr (MB == 2) part[(w * RW + 16 + r) * 64 + lane] = acc1[r];
         }
+        if constexpr (LN_IN) {
+            if (lane < 32) { lnst[(w * 2) * 32 + lane] = ln_s1; lnst[(w * 2 + 1) * 32 + lane] = ln_s2; }
+        }
         __syncthreads();
+        if constexpr (LN_IN) {                                 // the parts of the reduction in wave order, like the accumulators
+            ln_s1 = lnst[(ntile * KSPLIT * 2) * 32 + (lane & 31)];
+            ln_s2 = lnst[(ntile * KSPLIT * 2 + 1) * 32 + (lane & 31)];
+#pragma unroll
+            for (int j = 1; j < KSPLIT; ++j) {
+                ln_s1 += lnst[((ntile * KSPLIT + j) * 2) * 32 + (lane & 31)];
+                ln_s2 += lnst[((ntile * KSPLIT + j) * 2 + 1) * 32 + (lane & 31)];
+            }
+        }
+        if constexpr (LN_IN) {
+            const float inv_c = 1.0f / (float)a.Cin;
+            ln_mean = ln_s1 * inv_c;
+            ln_rstd = 1.0f / sqrtf(fmaxf(ln_s2 * inv_c - ln_mean * ln_mean, 0.f) + a.ln_eps);
+        }
 #pragma unroll
         for (int gi = 0; gi < NG; ++gi) {
             float v[4];
@@ -409,6 +436,11 @@ __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void lin_kernel(LinArgs a)
             finish4(v, gi);
         }
     } else {
+        if constexpr (LN_IN) {
+            const float inv_c = 1.0f / (float)a.Cin;
+            ln_mean = ln_s1 * inv_c;
+            ln_rstd = 1.0f / sqrtf(fmaxf(ln_s2 * inv_c - ln_mean * ln_mean, 0.f) + a.ln_eps);
+        }
 #pragma unroll
         for (int gi = 0; gi < NG; ++gi) {
             float v[4];
@@ -471,7 +503,7 @@ struct Host { std::vector<float> v; std::vector<int64_t> shape; };
 struct Lin { float* wt = nullptr; float* bias = nullptr; int Cin = 0, Cout = 0, K = 1; };
 struct Norm { float* g = nullptr; float* b = nullptr; };
 struct Resnet { Lin conv1, conv2, res; Norm n1, n2; };
-struct Transformer { Lin qkv, out, w1, w2; Norm n1, n3; };
+struct Transformer { Lin qkv, out, w1, w2; float *qkv_rsum = nullptr, *w1_rsum = nullptr; };   // norm1 / norm3 folded into qkv / w1
 struct Stage { Resnet res; Transformer tf[kBlocks]; Lin tail; bool has_tail = false; };
 
 }  // namespace
@@ -486,7 +518,7 @@ struct s3cfm {
     Norm final_norm;
     float *freq = nullptr, *t_w1 = nullptr, *t_b1 = nullptr, *t_w2 = nullptr, *t_b2 = nullptr, *mlp_w = nullptr, *mlp_b = nullptr;
     float *emb = nullptr, *th = nullptr, *temb = nullptr, *tvec = nullptr;
-    float *IN = nullptr, *X = nullptr, *Y = nullptr, *Z = nullptr, *CAT = nullptr, *N = nullptr, *QK = nullptr, *VT = nullptr, *O = nullptr, *H = nullptr,
+    float *IN = nullptr, *X = nullptr, *Y = nullptr, *Z = nullptr, *CAT = nullptr, *QK = nullptr, *VT = nullptr, *O = nullptr, *H = nullptr,
           *D = nullptr;
 };
 
@@ -524,6 +556,29 @@ int make_lin(s3cfm* h, Lin* l, const std::string& name, int Cout, int Cin, int K
     }
     return upload(h, &l->bias, b.data(), Cout);
 }
+// Linear [Cout][Cin] (+ bias) applied to LayerNorm(x) with gain gamma and shift beta -> what lin_kernel's folded form takes
+// (LinArgs::rsum): W' = W diag(gamma) in tile order, b' = b + W beta, rsum = row sums of W'; sums in double
+int make_lin_ln(s3cfm* h, Lin* l, float** rsum, const std::vector<float>& w, const std::vector<float>* bias, int Cout, int Cin,
+                const std::string& norm) {
+    const Host *g, *b;
+    if (get(h, norm + ".weight", {Cin}, &g) || get(h, norm + ".bias", {Cin}, &b)) return 1;
+    std::vector<float> wf((size_t)Cout * Cin), bf(Cout), rs(Cout);
+    for (int o = 0; o < Cout; ++o) {
+        double sb = bias ? (double)(*bias)[o] : 0.0, sr = 0.0;
+        for (int c = 0; c < Cin; ++c) {
+            const float wv = w[(size_t)o * Cin + c] * g->v[c];
+            wf[(size_t)o * Cin + c] = wv;
+            sr += (double)wv;
+            sb += (double)w[(size_t)o * Cin + c] * (double)b->v[c];
+        }
+        bf[o] = (float)sb;
+        rs[o] = (float)sr;
+    }
+    l->Cin = Cin; l->Cout = Cout; l->K = 1;
+    const std::vector<float> t = s3_tile_conv_weights(wf.data(), Cout, Cin, 1);
+    return upload(h, &l->wt, t.data(), t.size()) || upload(h, &l->bias, bf.data(), Cout) || upload(h, rsum, rs.data(), Cout);
+}
+
 int make_norm(s3cfm* h, Norm* n, const std::string& name) {
     const Host *g, *b;
     if (get(h, name + ".weight", {kC}, &g) || get(h, name + ".bias", {kC}, &b)) return 1;
@@ -534,6 +589,8 @@ int make_norm(s3cfm* h, Norm* n, const std::string& name) {
 
 int launch_lin(const LinArgs& a, int out_act, int rows, hipStream_t st) {
     S3_REQUIRE(a.Cin % 64 == 0 && a.x != a.y, "linear layer: input channels must be a multiple of 64 and the output a different tensor");
+    S3_REQUIRE(!a.rsum || (a.K == 1 && a.pad == 0 && (out_act == OUT_NONE || out_act == OUT_GELU)),
+               "linear layer: a folded LayerNorm needs a one-tap layer without or with GELU");
     const int L = a.L, mb = (a.CoutPad + 63) / 64;
     // enough 64 x 128 tiles to give every CU several workgroups: no split of the reduction
     static const int wide_min = getenv("S3CFM_WIDE_MIN") ? atoi(getenv("S3CFM_WIDE_MIN")) : 1024;
@@ -555,12 +612,14 @@ int launch_lin(const LinArgs& a, int out_act, int rows, hipStream_t st) {
     }
     const int ntw = ks == 8 ? 1 : 4 / ks;
     const dim3 grid((L + 32 * ntw - 1) / (32 * ntw), blocks == 2 ? mb : a.CoutPad / 32, rows), block(ks == 8 ? 512 : 256);
-#define S3_LIN_LAUNCH(KS, MB)                                                                                      \
-    do {                                                                                                           \
-        if (out_act == OUT_GELU) hipLaunchKernelGGL((lin_kernel<KS, MB, OUT_GELU>), grid, block, 0, st, a);        \
-        else if (out_act == OUT_SWISH) hipLaunchKernelGGL((lin_kernel<KS, MB, OUT_SWISH>), grid, block, 0, st, a); \
-        else if (out_act == OUT_LRELU) hipLaunchKernelGGL((lin_kernel<KS, MB, OUT_LRELU>), grid, block, 0, st, a); \
-        else hipLaunchKernelGGL((lin_kernel<KS, MB, OUT_NONE>), grid, block, 0, st, a);                            \
+#define S3_LIN_LAUNCH(KS, MB)                                                                                             \
+    do {                                                                                                                  \
+        if (a.rsum && out_act == OUT_GELU) hipLaunchKernelGGL((lin_kernel<KS, MB, OUT_GELU, true>), grid, block, 0, st, a);   \
+        else if (a.rsum) hipLaunchKernelGGL((lin_kernel<KS, MB, OUT_NONE, true>), grid, block, 0, st, a);                     \
+        else if (out_act == OUT_GELU) hipLaunchKernelGGL((lin_kernel<KS, MB, OUT_GELU, false>), grid, block, 0, st, a);       \
+        else if (out_act == OUT_SWISH) hipLaunchKernelGGL((lin_kernel<KS, MB, OUT_SWISH, false>), grid, block, 0, st, a);     \
+        else if (out_act == OUT_LRELU) hipLaunchKernelGGL((lin_kernel<KS, MB, OUT_LRELU, false>), grid, block, 0, st, a);     \
+        else hipLaunchKernelGGL((lin_kernel<KS, MB, OUT_NONE, false>), grid, block, 0, st, a);                                \
     } while (0)
     if (blocks == 1) S3_LIN_LAUNCH(4, 1);
     else if (ks == 8) S3_LIN_LAUNCH(8, 2);
@@ -599,7 +658,7 @@ int launch_attn(const AttnArgs& a, hipStream_t st) {
 
 // y[row][Cout][L] = out_act(conv(x[row][Cin][L])) (+ res) on both rows; pad = zero frames on the left.  y must not be x.
 int run_lin(const s3cfm* h, const Lin& l, const float* x, int x_rows, float* y, int y_rows, int L, int pad, int out_act, const float* res,
-            hipStream_t st, float* yt = nullptr, int yt_from = 0) {
+            hipStream_t st, float* yt = nullptr, int yt_from = 0, const float* rsum = nullptr) {
     LinArgs a{};
     a.x = x; a.x_bs = (size_t)x_rows * h->ld; a.x_ld = h->ld;
     a.wt = l.wt; a.bias = l.bias;
@@ -607,6 +666,7 @@ int run_lin(const s3cfm* h, const Lin& l, const float* x, int x_rows, float* y, 
     a.res = res;
     a.yt = yt; a.yt_bs = (size_t)h->ld * kVtLd; a.yt_ld = kVtLd; a.yt_from = yt_from;
     a.Cin = l.Cin; a.Cout = l.Cout; a.CoutPad = (l.Cout + 31) / 32 * 32; a.K = l.K; a.pad = pad; a.L = L;
+    a.rsum = rsum; a.ln_eps = 1e-5f;
     return launch_lin(a, out_act, kRows, st);
 }
 
@@ -633,14 +693,13 @@ int run_resnet(s3cfm* h, const Resnet& r, const float* x, int x_rows, const floa
 // BasicTransformerBlock.forward (matcha/transformer.py:243-316) on X [row][256][L], in place
 int run_transformer(s3cfm* h, const Transformer& b, int L, hipStream_t st) {
     const int ld = h->ld;
-    if (run_ln(h, LN_PLAIN, h->X, h->N, L, b.n1, nullptr, st)) return 1;
-    // q and k channel-major into QK, v frame-major into VT
-    if (run_lin(h, b.qkv, h->N, kC, h->QK, 2 * kInner, L, 0, OUT_NONE, nullptr, st, h->VT, 2 * kInner)) return 1;
+    // norm1 rides in the q/k/v projection (LinArgs::rsum); q and k channel-major into QK, v frame-major into VT
+    if (run_lin(h, b.qkv, h->X, kC, h->QK, 2 * kInner, L, 0, OUT_NONE, nullptr, st, h->VT, 2 * kInner, b.qkv_rsum)) return 1;
     AttnArgs at{h->QK, h->QK + (size_t)kInner * ld, (size_t)2 * kInner * ld, ld, h->VT, (size_t)ld * kVtLd, h->O, (size_t)kInner * ld, L};
     if (launch_attn(at, st)) return 1;
     if (run_lin(h, b.out, h->O, kInner, h->X, kC, L, 0, OUT_NONE, h->X, st)) return 1;
-    if (run_ln(h, LN_PLAIN, h->X, h->N, L, b.n3, nullptr, st)) return 1;
-    if (run_lin(h, b.w1, h->N, kC, h->H, kFf, L, 0, OUT_GELU, nullptr, st)) return 1;
+    // norm3 rides in the first feed-forward layer
+    if (run_lin(h, b.w1, h->X, kC, h->H, kFf, L, 0, OUT_GELU, nullptr, st, nullptr, 0, b.w1_rsum)) return 1;
     return run_lin(h, b.w2, h->H, kFf, h->X, kC, L, 0, OUT_NONE, h->X, st);
 }
 
@@ -754,13 +813,12 @@ extern "C" int s3cfm_finalize(s3cfm* h) {
             wst.insert(wst.end(), wq->v.begin(), wq->v.end());
             wst.insert(wst.end(), wk->v.begin(), wk->v.end());
             wst.insert(wst.end(), wv->v.begin(), wv->v.end());
-            const std::vector<float> t = s3_tile_conv_weights(wst.data(), 3 * kInner, kC, 1);
-            const std::vector<float> zero(3 * kInner, 0.f);
-            tf.qkv.Cin = kC; tf.qkv.Cout = 3 * kInner; tf.qkv.K = 1;
-            if (upload(h, &tf.qkv.wt, t.data(), t.size()) || upload(h, &tf.qkv.bias, zero.data(), zero.size())) return 1;
+            if (make_lin_ln(h, &tf.qkv, &tf.qkv_rsum, wst, nullptr, 3 * kInner, kC, tp + "norm1")) return 1;
             if (make_lin(h, &tf.out, tp + "attn1.to_out.0", kC, kInner, 0, true)) return 1;
-            if (make_lin(h, &tf.w1, tp + "ff.net.0.proj", kFf, kC, 0, true) || make_lin(h, &tf.w2, tp + "ff.net.2", kC, kFf, 0, true)) return 1;
-            if (make_norm(h, &tf.n1, tp + "norm1") || make_norm(h, &tf.n3, tp + "norm3")) return 1;
+            const Host *w1, *b1;
+            if (get(h, tp + "ff.net.0.proj.weight", {kFf, kC}, &w1) || get(h, tp + "ff.net.0.proj.bias", {kFf}, &b1)) return 1;
+            if (make_lin_ln(h, &tf.w1, &tf.w1_rsum, w1->v, &b1->v, kFf, kC, tp + "norm3")) return 1;
+            if (make_lin(h, &tf.w2, tp + "ff.net.2", kC, kFf, 0, true)) return 1;
         }
         sg.has_tail = s == 0 || s == kStages - 1;
         if (sg.has_tail && make_lin(h, &sg.tail, sp + "2", kC, kC, 3, true)) return 1;
@@ -776,7 +834,7 @@ extern "C" int s3cfm_finalize(s3cfm* h) {
     const size_t ld = h->ld;
     if (dalloc(h, &h->emb, kIn) || dalloc(h, &h->th, kTime) || dalloc(h, &h->temb, kTime) || dalloc(h, &h->tvec, kStages * kC)) return 1;
     if (dalloc(h, &h->IN, kRows * kIn * ld) || dalloc(h, &h->CAT, kRows * 2 * kC * ld) || dalloc(h, &h->D, kRows * kMel * ld)) return 1;
-    for (float** p : {&h->X, &h->Y, &h->Z, &h->N})
+    for (float** p : {&h->X, &h->Y, &h->Z})
         if (dalloc(h, p, kRows * kC * ld)) return 1;
     if (dalloc(h, &h->QK, kRows * 2 * kInner * ld) || dalloc(h, &h->VT, kRows * kVtLd * ld) || dalloc(h, &h->O, kRows * kInner * ld) ||
         dalloc(h, &h->H, kRows * kFf * ld))
@@ -860,15 +918,31 @@ int time_launches(int iters, hipStream_t st, float* avg_us, const std::function<
 
 extern "C" int s3cfm_op_linear(const float* x_dev, int32_t Cin, int32_t L, int32_t ld, const float* w_host, const float* bias_host, int32_t Cout,
                                int32_t K, int32_t pad, int32_t gelu, const float* res_dev, float* y_dev, float* yt_dev, int32_t yt_from,
-                               int32_t iters, float* avg_us, void* stream) {
+                               const float* ln_gamma_host, const float* ln_beta_host, int32_t iters, float* avg_us, void* stream) {
     S3_REQUIRE(x_dev && w_host && bias_host && y_dev && Cin >= 64 && Cout >= 1 && K >= 1 && L >= 1 && ld >= L && iters >= 0, "bad arguments");
     S3_REQUIRE(!yt_dev || (yt_from % 32 == 0 && Cout - yt_from == kInner), "the frame-major part must be the last 512 channels");
+    S3_REQUIRE(!ln_gamma_host == !ln_beta_host && (!ln_gamma_host || K == 1), "a folded LayerNorm needs gain and shift and a one-tap layer");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const std::vector<float> t = s3_tile_conv_weights(w_host, Cout, Cin, K);
-    DevBuf wt, bias;
-    if (wt.alloc(t.size()) || bias.alloc(Cout)) return 1;
+    // the fold of make_lin_ln: W' = W diag(gamma), b' = b + W beta, rsum = row sums of W'
+    std::vector<float> wf(w_host, w_host + (size_t)Cout * Cin * K), bf(bias_host, bias_host + Cout), rs(Cout, 0.f);
+    if (ln_gamma_host) {
+        for (int o = 0; o < Cout; ++o) {
+            double sb = bias_host[o], sr = 0.0;
+            for (int c = 0; c < Cin; ++c) {
+                wf[(size_t)o * Cin + c] = w_host[(size_t)o * Cin + c] * ln_gamma_host[c];
+                sr += (double)wf[(size_t)o * Cin + c];
+                sb += (double)w_host[(size_t)o * Cin + c] * (double)ln_beta_host[c];
+            }
+            bf[o] = (float)sb;
+            rs[o] = (float)sr;
+        }
+    }
+    const std::vector<float> t = s3_tile_conv_weights(wf.data(), Cout, Cin, K);
+    DevBuf wt, bias, rsum;
+    if (wt.alloc(t.size()) || bias.alloc(Cout) || rsum.alloc(Cout)) return 1;
     S3_HIP_CHECK(hipMemcpy(wt.p, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
-    S3_HIP_CHECK(hipMemcpy(bias.p, bias_host, Cout * sizeof(float), hipMemcpyHostToDevice));
+    S3_HIP_CHECK(hipMemcpy(bias.p, bf.data(), Cout * sizeof(float), hipMemcpyHostToDevice));
+    S3_HIP_CHECK(hipMemcpy(rsum.p, rs.data(), Cout * sizeof(float), hipMemcpyHostToDevice));
     LinArgs a{};
     a.x = x_dev; a.x_bs = (size_t)Cin * ld; a.x_ld = ld;
     a.wt = wt.p; a.bias = bias.p;
@@ -876,6 +950,7 @@ extern "C" int s3cfm_op_linear(const float* x_dev, int32_t Cin, int32_t L, int32
     a.res = res_dev;
     a.yt = yt_dev; a.yt_bs = (size_t)ld * kVtLd; a.yt_ld = kVtLd; a.yt_from = yt_from;
     a.Cin = Cin; a.Cout = Cout; a.CoutPad = (Cout + 31) / 32 * 32; a.K = K; a.pad = pad; a.L = L;
+    a.rsum = ln_gamma_host ? rsum.p : nullptr; a.ln_eps = 1e-5f;
     const int rc = time_launches(iters, st, avg_us, [&]() { return launch_lin(a, gelu ? OUT_GELU : OUT_NONE, kRows, st); });
     S3_HIP_CHECK(hipStreamSynchronize(st));
     return rc;

@@ -74,6 +74,10 @@ int launch_bgemm(const BGemm& g, int batch, hipStream_t st);
 // One launch of the small-tile matrix kernel for linear layers and short convolutions (lin_kernel, cfm_decoder.hip):
 // y[z][co][n] = out_act(bias[co] + sum_{tap, ci} W[co][ci][tap] x[z][ci][n + tap - pad]) (+ res[z][co][n]) for z < rows;
 // x outside [0, L) reads as zero, y must not be x, Cin a multiple of 64.
+// With rsum (one-tap layers only) the layer takes LayerNorm(x) over the Cin channels of a frame instead of x: the caller folds
+// the norm's gain into the weights (W' = W diag(gamma)), its shift into the bias (b' = b + W beta) and passes rsum[co] =
+// sum_ci W'[co][ci]; the kernel multiplies the raw x, gathers each frame's sum and sum of squares from the operands it
+// loads anyway, and finishes y = rstd (W' x - mean rsum) + b'.
 struct LinArgs {
     const float* x; size_t x_bs; int x_ld;
     const float* wt; const float* bias;      // wt in tile order (ConvArgs::wt)
@@ -81,6 +85,7 @@ struct LinArgs {
     const float* res;                        // layout of y; may be y itself
     float* yt; size_t yt_bs; int yt_ld, yt_from;   // yt not null: channels >= yt_from go to yt[z][n][co - yt_from] (frame-major)
     int Cin, Cout, CoutPad, K, pad, L;
+    const float* rsum; float ln_eps;         // rsum not null: LayerNorm of the input folded into this layer
 };
 enum { OUT_NONE = 0, OUT_GELU = 1, OUT_SWISH = 2, OUT_LRELU = 3 };   // OUT_LRELU: slope 0.01
 int launch_lin(const LinArgs& a, int out_act, int rows, hipStream_t st);

@@ -53,10 +53,13 @@ int s3cfm_solve(s3cfm* h, const float* mu_dev, const float* spks_dev, const floa
  * The linear layers and causal convolutions (decoder.py:94-97 `CausalConv1d`, every `nn.Linear` of the transformer blocks):
  * y[row][co][n] = act(bias[co] + sum_{tap, ci} w[co][ci][tap] x[row][ci][n + tap - pad]) (+ res), w_host [Cout][Cin][K] and
  * bias_host [Cout] in host memory, act = GELU (erf form) when `gelu` is set.  With yt_dev, channels from yt_from on (the last
- * 512) go frame-major to yt_dev [2][ld][576] instead, the layout the attention takes V in, and y_dev holds yt_from channels. */
+ * 512) go frame-major to yt_dev [2][ld][576] instead, the layout the attention takes V in, and y_dev holds yt_from channels.
+ * With ln_gamma_host / ln_beta_host [Cin] (K = 1) the layer is applied to LayerNorm(x) over the channels of a frame (eps 1e-5,
+ * `nn.LayerNorm` as matcha/transformer.py:178, 206 builds norm1 and norm3): the form in which the transformer blocks' norms
+ * ride in the q/k/v projection and the first feed-forward layer. */
 int s3cfm_op_linear(const float* x_dev, int32_t Cin, int32_t L, int32_t ld, const float* w_host, const float* bias_host, int32_t Cout,
                     int32_t K, int32_t pad, int32_t gelu, const float* res_dev, float* y_dev, float* yt_dev, int32_t yt_from,
-                    int32_t iters, float* avg_us, void* stream);
+                    const float* ln_gamma_host, const float* ln_beta_host, int32_t iters, float* avg_us, void* stream);
 
 /* Self-attention of a transformer block (the diffusers default processor as matcha/transformer.py:267-273 calls it: 8 heads x
  * 64, softmax(q k^T / 8) v, every frame attends to every frame): qk_dev [2][1024][ld] (q in channels 0..511, k in 512..1023,

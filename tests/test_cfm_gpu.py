@@ -146,6 +146,33 @@ def test_linear_kernel_against_fp64(Cin, Cout, K, pad, L):
     assert (y.double().cpu() - want).abs().max().item() < 2e-5
 
 
+@pytest.mark.parametrize("Cout,L,offset", [(1536, 1000, 0.0), (1024, 333, 3.0), (1024, 4200, -1.0), (256, 40, 0.5)])
+def test_linear_kernel_with_the_layer_norm_folded_in(Cout, L, offset):
+    """norm1 / norm3 of a transformer block ride in the layer that consumes them (LinArgs::rsum): W LayerNorm(x) + b against
+    fp64, with channel means away from zero (the folded form subtracts mean * row-sum after the product), for every
+    workgroup form, with GELU and with the frame-major part."""
+    from chatterbox_vllm_amd.cfm_decoder import linear_op
+    g = torch.Generator().manual_seed(Cout + L)
+    x = 2.0 * torch.randn(2, 256, L, generator=g) + offset
+    w = torch.randn(Cout, 256, 1, generator=g) / 16
+    b = torch.randn(Cout, generator=g)
+    gamma = 1.0 + 0.2 * torch.randn(256, generator=g)
+    beta = 0.3 * torch.randn(256, generator=g)
+    n = torch.nn.functional.layer_norm(x.double().transpose(1, 2), (256,), gamma.double(), beta.double(), 1e-5).transpose(1, 2)
+    want = torch.nn.functional.conv1d(n, w.double(), b.double())
+    gelu = Cout == 1024
+    if gelu:
+        want = torch.nn.functional.gelu(want)
+    ld = (L + 63) // 64 * 64 + 64
+    xd = torch.zeros(2, 256, ld, device="cuda")
+    xd[:, :, :L] = x.cuda()
+    y, vt, _ = linear_op(xd[:, :, :L], w, b, gelu=gelu, v_from=1024 if Cout == 1536 else None, ln=(gamma, beta))
+    if Cout == 1536:
+        assert (vt.double().cpu() - want[:, 1024:].transpose(1, 2)).abs().max().item() < 2e-5
+        want = want[:, :1024]
+    assert (y.double().cpu() - want).abs().max().item() < 2e-5
+
+
 def test_qkv_projection_writes_v_frame_major():
     from chatterbox_vllm_amd.cfm_decoder import linear_op
     L = 210

@@ -260,7 +260,7 @@ def vocoder_leg(device, batch=8, frames=500, iters=5):
             prof = json.load(fh)
         h = hashlib.sha256()
         d = os.path.join(ROOT, "chatterbox_vllm_amd", "csrc_s3gen")
-        for name in ("hift_common.h", "hift_engine.hip", "hift_kernels.hip"):     # the vocoder's own sources
+        for name in ("hift_engine.hip", "hift_kernels.hip"):     # the vocoder's kernels and their launch logic
             with open(os.path.join(d, name), "rb") as fh:
                 h.update(fh.read())
         if prof.get("kernel_source_sha16") == h.hexdigest()[:16] and (batch, frames) == (8, 500):

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def source_sha():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "chatterbox_vllm_amd", "csrc_s3gen")
-    for name in ("hift_common.h", "hift_engine.hip", "hift_kernels.hip"):     # the vocoder's own sources
+    for name in ("hift_engine.hip", "hift_kernels.hip"):     # the vocoder's kernels and their launch logic
         if True:
             with open(os.path.join(d, name), "rb") as fh:
                 h.update(fh.read())

@@ -123,10 +123,11 @@ def test_token_to_waveform_chain_with_the_packaged_decoder(sd):
 
 
 @pytest.mark.parametrize("Cin,Cout,K,pad,L", [(256, 256, 1, 0, 1000), (320, 256, 3, 2, 77), (1024, 256, 1, 0, 333), (512, 256, 3, 2, 50),
-                                               (256, 1024, 1, 0, 1), (256, 80, 1, 0, 97), (256, 1024, 1, 0, 4200), (256, 1024, 1, 0, 1000), (256, 1536, 1, 0, 1000)])
+                                               (256, 1024, 1, 0, 1), (256, 80, 1, 0, 97), (256, 1024, 1, 0, 4200), (256, 1024, 1, 0, 1000), (256, 1536, 1, 0, 1000), (1024, 256, 1, 0, 1100)])
 def test_linear_kernel_against_fp64(Cin, Cout, K, pad, L):
     """Every shape class the estimator launches: the four workgroup forms (8-, 4- and 2-way split of the reduction, none:
-    chosen by the number of tiles), causal taps, ragged lengths, 80 output channels, GELU and the residual add."""
+    chosen by the number of tiles; 1100 frames x 256 channels takes one 32-channel block per wave), causal taps, ragged
+    lengths, 80 output channels, GELU and the residual add."""
     from chatterbox_vllm_amd.cfm_decoder import linear_op
     g = torch.Generator().manual_seed(Cin + Cout + K + L)
     x = torch.randn(2, Cin, L, generator=g)
@@ -188,10 +189,11 @@ def test_qkv_projection_writes_v_frame_major():
     assert (vt.double().cpu() - want[:, 1024:].transpose(1, 2)).abs().max().item() < 1e-5
 
 
-@pytest.mark.parametrize("L", [1, 31, 32, 100, 129, 1000, 2101])
+@pytest.mark.parametrize("L", [1, 31, 32, 100, 129, 1000, 1100, 2101])
 def test_attention_kernel_against_fp64(L):
     """softmax(q k^T / 8) v per head against fp64, lengths around the 32-key tile and the four-wave split, with score
-    spreads of tens of units so that the running maximum moves."""
+    spreads of tens of units so that the running maximum moves; 1000, 1100 and 2101 frames make the launcher pick two,
+    three and one query tiles per wave."""
     from chatterbox_vllm_amd.cfm_decoder import attention_op
     g = torch.Generator().manual_seed(L)
     q = 2.0 * torch.randn(2, 512, L, generator=g)

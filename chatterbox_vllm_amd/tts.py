@@ -9,12 +9,14 @@ Kept from src/chatterbox_vllm/tts.py of the reference: the constructor names
 sampling-parameter derivation (language clamp :350-356, CHATTERBOX_DETERMINISTIC :358-362,
 batch-wide max_tokens :372-393) and the id post-processing (:435-486).
 
-Scope: this package produces speech-token ids.  The waveform stages (S3Gen, alignment cap,
-RMS tail trim, tts.py:489-557) and the audio front end behind ``audio_prompt_path``
-(VoiceEncoder, S3Tokenizer) are not part of it: ``generate`` returns one 1-D int64 tensor of
-speech tokens per prompt, or, when a vocoder object with the reference's
-``inference(speech_tokens=, ref_dict=, n_timesteps=)`` method is attached as ``s3gen``, what
-that returns.
+Scope: ``generate`` returns one 1-D int64 tensor of speech tokens per prompt, or, when a
+token -> waveform object with the reference's ``inference(speech_tokens=, ref_dict=,
+n_timesteps=)`` method is attached as ``s3gen``, the waveform that returns (tts.py:489-493).
+``from_local`` attaches this package's ``S3Token2Wav`` (s3gen.py) when the checkpoint
+directory holds ``s3gen.safetensors``; ``from_synthetic(with_s3gen=True)`` does on seeded
+weights.  Not part of the package: the alignment cap and RMS tail trim applied to the
+waveform afterwards (tts.py:495-557) and the audio front end behind ``audio_prompt_path``
+(VoiceEncoder, S3Tokenizer, the reference-audio side of S3Gen).
 """
 from __future__ import annotations
 

@@ -14,8 +14,9 @@ token -> waveform object with the reference's ``inference(speech_tokens=, ref_di
 n_timesteps=)`` method is attached as ``s3gen``, the waveform that returns (tts.py:489-493).
 ``from_local`` attaches this package's ``S3Token2Wav`` (s3gen.py) when the checkpoint
 directory holds ``s3gen.safetensors``; ``from_synthetic(with_s3gen=True)`` does on seeded
-weights.  Not part of the package: the alignment cap and RMS tail trim applied to the
-waveform afterwards (tts.py:495-557) and the audio front end behind ``audio_prompt_path``
+weights; the waveform then gets the reference's alignment cap and RMS tail trim
+(``postprocess_waveform``, tts.py:495-541).  Not part of the package: the optional VAD trim
+(tts.py:543-555, torchaudio) and the audio front end behind ``audio_prompt_path``
 (VoiceEncoder, S3Tokenizer, the reference-audio side of S3Gen).
 """
 from __future__ import annotations
@@ -59,6 +60,39 @@ def postprocess_speech_ids(token_ids: Sequence[int], prompt: str = "", tail_crop
     if prompt:
         ids = ids[: guard_cap(prompt)]
     return torch.tensor(ids, dtype=torch.int64)
+
+
+def postprocess_waveform(wav: torch.Tensor, n_tokens: int, sr: int = S3GEN_SR) -> torch.Tensor:
+    """What the reference does to a rendered waveform [1, N] before returning it (tts.py:495-541), same environment switches:
+    cut to the duration the speech tokens stand for (25 tokens per second, CHATTERBOX_ALIGN_HARD / _ALIGN_SAFETY_MS), then cut
+    the tail after the last 50 ms window (20 ms hop) whose RMS is within 35 dB of the loudest one, plus 50 ms
+    (CHATTERBOX_TAIL_TRIM, _TAIL_TRIM_DB, _TAIL_TRIM_DB_REL, _TAIL_TRIM_SAFETY_MS, _RMS_WINDOW_MS, _RMS_HOP_MS).  The optional
+    VAD trim behind CHATTERBOX_VAD_TRIM (tts.py:543-555) needs torchaudio and is not reproduced."""
+    on = lambda name, default: os.environ.get(name, default).lower() in ("1", "true", "yes", "on")
+    if wav is None or wav.numel() == 0:
+        return wav
+    if on("CHATTERBOX_ALIGN_HARD", "1"):
+        expected = int(round(n_tokens * (sr / 25)))
+        safety = max(0, int(sr * int(os.environ.get("CHATTERBOX_ALIGN_SAFETY_MS", "0")) / 1000))
+        wav = wav[:, : min(wav.shape[1], expected + safety)]
+    if on("CHATTERBOX_TAIL_TRIM", "1") and wav.numel() > 0:
+        frame_len = max(1, int(sr * int(os.environ.get("CHATTERBOX_RMS_WINDOW_MS", "50")) / 1000))
+        hop_len = max(1, int(sr * int(os.environ.get("CHATTERBOX_RMS_HOP_MS", "20")) / 1000))
+        if wav.shape[1] >= frame_len:
+            x2 = (wav.unsqueeze(0) ** 2).view(1, 1, -1)
+            kernel = torch.ones(1, 1, frame_len, device=wav.device, dtype=wav.dtype) / frame_len
+            rms = torch.sqrt(torch.nn.functional.conv1d(x2, kernel, stride=hop_len)).reshape(-1)
+            peak = float(rms.max().item()) if rms.numel() > 0 else 0.0
+            if peak > 0:
+                thr = peak * (10.0 ** (float(os.environ.get("CHATTERBOX_TAIL_TRIM_DB_REL", "-35")) / 20.0))
+            else:
+                thr = 10.0 ** (float(os.environ.get("CHATTERBOX_TAIL_TRIM_DB", "-42")) / 20.0)
+            active = torch.where(rms > thr)[0]
+            if active.numel() > 0:
+                safety = int(sr * int(os.environ.get("CHATTERBOX_TAIL_TRIM_SAFETY_MS", "50")) / 1000)
+                cut = min(wav.shape[1], (int(active[-1].item()) + 1) * hop_len + safety)
+                wav = wav[:, :cut]
+    return wav
 
 
 class ChatterboxTTS:
@@ -282,7 +316,7 @@ class ChatterboxTTS:
                 if self.s3gen is not None:
                     wav, _ = self.s3gen.inference(speech_tokens=toks.to(self.target_device), ref_dict=s3gen_ref,
                                                   n_timesteps=diffusion_steps)
-                    results.append(wav.cpu())
+                    results.append(postprocess_waveform(wav, int(toks.numel()), self.sr).cpu())
                 else:
                     results.append(toks)
         return results

@@ -267,3 +267,22 @@ def test_from_local_reads_a_checkpoint_directory(tmp_path, golden_dir, monkeypat
     monkeypatch.chdir(tmp_path)
     with pytest.raises(FileNotFoundError):
         T.ChatterboxTTS.from_local(str(tmp_path))
+
+
+def test_waveform_post_processing_follows_the_reference(monkeypatch):
+    """tts.py:495-541: the waveform is cut to 960 samples per speech token, then after the last 50 ms window (20 ms hop) whose
+    RMS is within 35 dB of the loudest window, plus 50 ms."""
+    from chatterbox_vllm_amd.tts import postprocess_waveform
+    sr = 24000
+    g = torch.Generator().manual_seed(0)
+    wav = torch.zeros(1, 30 * 960 + 500)
+    wav[0, : 12000] = 0.3 * torch.randn(12000, generator=g)                 # half a second of signal, then silence
+    out = postprocess_waveform(wav, 30, sr)
+    # the last active window starts at hop index 24 (24 * 480 = 11520 < 12000): cut = 25 * 480 + 1200
+    assert out.shape == (1, 25 * 480 + 1200) and torch.equal(out, wav[:, : out.shape[1]])
+    loud = 0.3 * torch.randn(1, 30 * 960 + 500, generator=g)
+    assert postprocess_waveform(loud, 30, sr).shape == (1, 30 * 960)      # alignment cap only
+    monkeypatch.setenv("CHATTERBOX_ALIGN_HARD", "0")
+    monkeypatch.setenv("CHATTERBOX_TAIL_TRIM", "0")
+    assert postprocess_waveform(wav, 30, sr).shape == wav.shape
+    assert postprocess_waveform(torch.zeros(1, 0), 0, sr).numel() == 0

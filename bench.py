@@ -373,6 +373,40 @@ def token_to_waveform_leg(device, prompt_tokens=250, new_tokens=250, iters=3):
             "parity": "flow decoder restatement unpinned; encoder and vocoder pinned by reference outputs"}
 
 
+def s3gen_job_leg(device, lengths, prompt_tokens=250):
+    """The second half of the reference's benchmark.py for the same job: every chunk's speech tokens through the token ->
+    waveform chain, one utterance at a time as the reference runs it (tts.py:428-557), with a 10 s voice prompt.  The token
+    counts are the ones the T3 leg generated for the job's chunks; the token values and all weights are seeded synthetic.
+    Reported beside the T3 time so that the whole text -> waveform job has a number (the reference's README reports the two
+    times for its run, README.md:150-153)."""
+    from chatterbox_vllm_amd import cfm_weights as CW, flow_weights as FW, hift_weights as HW
+    from chatterbox_vllm_amd.s3gen import S3Token2Wav
+    flow_sd = dict(FW.synthetic_state_dict())
+    flow_sd.update(CW.synthetic_state_dict())
+    lengths = [n for n in lengths if n > 0]
+    s3 = S3Token2Wav(flow_sd, HW.synthetic_state_dict(), max_tokens=prompt_tokens + max(lengths), device=device)
+    g = torch.Generator().manual_seed(12)
+    dev = f"cuda:{device}"
+    ref = {"prompt_token": FW.synthetic_tokens(prompt_tokens, seed=3).view(1, -1),
+           "prompt_feat": (2.0 * torch.randn(1, 2 * prompt_tokens, 80, generator=g) - 4.0).to(dev),
+           "embedding": torch.randn(1, 192, generator=g).to(dev)}
+    toks = [torch.randint(0, 6561, (n,), generator=g).to(dev) for n in lengths]
+    s3.inference(toks[0], ref)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    samples = 0
+    for t in toks:
+        wav, _ = s3.inference(t, ref)
+        samples += wav.shape[1]
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    s3.shutdown()
+    return {"workload": f"S3Gen over the job's {len(lengths)} chunks ({sum(lengths)} speech tokens, {min(lengths)}-{max(lengths)} per chunk), "
+                        f"{prompt_tokens}-token voice prompt, 10 Euler steps, one utterance at a time, seeded synthetic weights",
+            "metric": "generated audio seconds per second", "value": round(samples / 24000 / dt, 1), "unit": "audio s/s",
+            "seconds": round(dt, 3), "audio_seconds": round(samples / 24000, 1), "dtype": "f32"}
+
+
 def extra_leg(args, device, sd_cache, workload, conc, quantization, repeat, label):
     """One short leg of another BASELINE configuration on this GPU: one warm-up pass, one timed pass, one event-timed
     pass.  Returns the record that goes under "other_configs"."""
@@ -648,6 +682,9 @@ def main():
         result["vocoder"] = vocoder_leg(local_rank)
         result["flow_decoder"] = flow_decoder_leg(local_rank)
         result["token_to_waveform"] = token_to_waveform_leg(local_rank)
+        # the job's own chunks through the waveform stages: ids below the stop / offset rules' reach, so the counts are the job's
+        result["s3gen_job"] = s3gen_job_leg(local_rank, [len(x) for x in last_ids])
+        result["s3gen_job"]["t3_seconds_same_job"] = round(result["ms_per_step"] / 1e3, 3)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.rehearse:   # the CPU leg is timed on the one-GPU run only
         cb, cpu_ids, sub = cpu_baseline(cfg, sd, job, conds, paired=paired)

@@ -373,38 +373,70 @@ def token_to_waveform_leg(device, prompt_tokens=250, new_tokens=250, iters=3):
             "parity": "flow decoder restatement unpinned; encoder and vocoder pinned by reference outputs"}
 
 
-def s3gen_job_leg(device, lengths, prompt_tokens=250):
+def s3gen_job_leg(device, lengths, prompt_tokens=250, workers=(1, 3)):
     """The second half of the reference's benchmark.py for the same job: every chunk's speech tokens through the token ->
-    waveform chain, one utterance at a time as the reference runs it (tts.py:428-557), with a 10 s voice prompt.  The token
-    counts are the ones the T3 leg generated for the job's chunks; the token values and all weights are seeded synthetic.
-    Reported beside the T3 time so that the whole text -> waveform job has a number (the reference's README reports the two
-    times for its run, README.md:150-153)."""
+    waveform chain with a 10 s voice prompt.  The token counts are the ones the T3 leg generated for the job's chunks; the
+    token values and all weights are seeded synthetic.  `value` is with one utterance at a time, as the reference runs it
+    (tts.py:428-557); `in_flight` repeats the job with several utterances in flight, each on its own chain (weights,
+    workspace, stream, host thread), chunks handed out longest first: the launches of one 20 s utterance leave CUs idle that
+    another utterance's launches can use.  Reported beside the T3 time so that the whole text -> waveform job has a number
+    (the reference's README reports the two times for its run, README.md:150-153)."""
+    import queue
+    import threading
     from chatterbox_vllm_amd import cfm_weights as CW, flow_weights as FW, hift_weights as HW
     from chatterbox_vllm_amd.s3gen import S3Token2Wav
     flow_sd = dict(FW.synthetic_state_dict())
     flow_sd.update(CW.synthetic_state_dict())
+    hift_sd = HW.synthetic_state_dict()
     lengths = [n for n in lengths if n > 0]
-    s3 = S3Token2Wav(flow_sd, HW.synthetic_state_dict(), max_tokens=prompt_tokens + max(lengths), device=device)
     g = torch.Generator().manual_seed(12)
     dev = f"cuda:{device}"
     ref = {"prompt_token": FW.synthetic_tokens(prompt_tokens, seed=3).view(1, -1),
            "prompt_feat": (2.0 * torch.randn(1, 2 * prompt_tokens, 80, generator=g) - 4.0).to(dev),
            "embedding": torch.randn(1, 192, generator=g).to(dev)}
     toks = [torch.randint(0, 6561, (n,), generator=g).to(dev) for n in lengths]
-    s3.inference(toks[0], ref)
-    torch.cuda.synchronize(device)
-    t0 = time.perf_counter()
-    samples = 0
-    for t in toks:
-        wav, _ = s3.inference(t, ref)
-        samples += wav.shape[1]
-    torch.cuda.synchronize(device)
-    dt = time.perf_counter() - t0
-    s3.shutdown()
-    return {"workload": f"S3Gen over the job's {len(lengths)} chunks ({sum(lengths)} speech tokens, {min(lengths)}-{max(lengths)} per chunk), "
-                        f"{prompt_tokens}-token voice prompt, 10 Euler steps, one utterance at a time, seeded synthetic weights",
-            "metric": "generated audio seconds per second", "value": round(samples / 24000 / dt, 1), "unit": "audio s/s",
-            "seconds": round(dt, 3), "audio_seconds": round(samples / 24000, 1), "dtype": "f32"}
+    chains, streams, runs = [], [], {}
+    for nw in workers:
+        while len(chains) < nw:
+            chains.append(S3Token2Wav(flow_sd, hift_sd, max_tokens=prompt_tokens + max(lengths), device=device))
+            streams.append(torch.cuda.Stream(device=dev))
+            with torch.cuda.stream(streams[-1]):
+                chains[-1].inference(toks[0], ref)
+        torch.cuda.synchronize(device)
+        q = queue.Queue()
+        for i in sorted(range(len(toks)), key=lambda i: -lengths[i]):
+            q.put(i)
+        samples = [0] * nw
+
+        def work(w):
+            with torch.cuda.stream(streams[w]):
+                while True:
+                    try:
+                        i = q.get_nowait()
+                    except queue.Empty:
+                        break
+                    wav, _ = chains[w].inference(toks[i], ref)
+                    samples[w] += wav.shape[1]
+                streams[w].synchronize()
+
+        t0 = time.perf_counter()
+        threads = [threading.Thread(target=work, args=(w,)) for w in range(nw)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        torch.cuda.synchronize(device)
+        runs[nw] = (time.perf_counter() - t0, sum(samples) / 24000)
+    for c in chains:
+        c.shutdown()
+    dt, audio = runs[workers[0]]
+    rec = {"workload": f"S3Gen over the job's {len(lengths)} chunks ({sum(lengths)} speech tokens, {min(lengths)}-{max(lengths)} per chunk), "
+                       f"{prompt_tokens}-token voice prompt, 10 Euler steps, seeded synthetic weights",
+           "metric": "generated audio seconds per second", "value": round(audio / dt, 1), "unit": "audio s/s",
+           "utterances_in_flight": workers[0], "seconds": round(dt, 3), "audio_seconds": round(audio, 1), "dtype": "f32"}
+    rec["in_flight"] = [{"utterances_in_flight": nw, "seconds": round(runs[nw][0], 3), "value": round(runs[nw][1] / runs[nw][0], 1)}
+                        for nw in workers[1:]]
+    return rec
 
 
 def extra_leg(args, device, sd_cache, workload, conc, quantization, repeat, label):

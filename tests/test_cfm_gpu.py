@@ -204,3 +204,42 @@ def test_attention_kernel_against_fp64(L):
     a = torch.softmax(qh.transpose(2, 3) @ kh / 8.0, dim=-1)                     # [2, 8, L, L]
     want = (vh @ a.transpose(2, 3)).reshape(2, 512, L)
     assert (o.double().cpu() - want).abs().max().item() < 2e-5
+
+
+def test_two_chains_in_flight_give_the_bits_of_one_at_a_time(sd):
+    """Several utterances in flight (bench.py's s3gen_job leg): two token -> waveform chains, each with its own handle set,
+    stream and host thread, running at the same time return bit for bit what one chain returns for the same utterances one
+    after the other."""
+    import threading
+    from chatterbox_vllm_amd import flow_weights as FW, hift_weights as HW
+    from chatterbox_vllm_amd.s3gen import S3Token2Wav
+    flow_sd = dict(FW.synthetic_state_dict())
+    flow_sd.update(sd)
+    hift_sd = HW.synthetic_state_dict()
+    g = torch.Generator().manual_seed(21)
+    ref = {"prompt_token": FW.synthetic_tokens(20, seed=3).view(1, -1), "prompt_feat": 2.0 * torch.randn(1, 40, 80, generator=g) - 4.0,
+           "embedding": torch.randn(1, 192, generator=g)}
+    toks = [FW.synthetic_tokens(n, seed=30 + n) for n in (35, 61, 18, 50)]
+    chains = []
+    for _ in range(2):
+        torch.manual_seed(9)                                     # both chains draw the same fixed noise
+        chains.append(S3Token2Wav(flow_sd, hift_sd, max_tokens=96))
+    want = [chains[0].inference(t, ref, n_timesteps=3, seed=5)[0].cpu() for t in toks]
+    got = [None] * len(toks)
+    streams = [torch.cuda.Stream() for _ in range(2)]
+
+    def work(w):
+        with torch.cuda.stream(streams[w]):
+            for i in range(w, len(toks), 2):
+                got[i] = chains[w].inference(toks[i], ref, n_timesteps=3, seed=5)[0]
+            streams[w].synchronize()
+
+    threads = [threading.Thread(target=work, args=(w,)) for w in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for a, b in zip(got, want):
+        assert torch.equal(a.cpu(), b)
+    for c in chains:
+        c.shutdown()

@@ -373,14 +373,16 @@ def token_to_waveform_leg(device, prompt_tokens=250, new_tokens=250, iters=3):
             "parity": "flow decoder restatement unpinned; encoder and vocoder pinned by reference outputs"}
 
 
-def s3gen_job_leg(device, lengths, prompt_tokens=250, workers=(1, 3)):
+def s3gen_job_leg(device, lengths, prompt_tokens=250, variants=((1, 1), (3, 1), (1, 8), (2, 4))):
     """The second half of the reference's benchmark.py for the same job: every chunk's speech tokens through the token ->
     waveform chain with a 10 s voice prompt.  The token counts are the ones the T3 leg generated for the job's chunks; the
     token values and all weights are seeded synthetic.  `value` is with one utterance at a time, as the reference runs it
-    (tts.py:428-557); `in_flight` repeats the job with several utterances in flight, each on its own chain (weights,
-    workspace, stream, host thread), chunks handed out longest first: the launches of one 20 s utterance leave CUs idle that
-    another utterance's launches can use.  Reported beside the T3 time so that the whole text -> waveform job has a number
-    (the reference's README reports the two times for its run, README.md:150-153)."""
+    (tts.py:428-557).  `variants` repeats the job as (utterances in flight, utterances per call): several utterances in
+    flight, each on its own chain (weights, workspace, stream, host thread), use the CUs that the launches of one 20 s
+    utterance leave idle; several chunks of similar length per call (S3Token2Wav.inference_batch) share the flow-matching
+    stage's launches, which fills the CUs inside each launch instead; chunks are handed out longest first.  Reported beside
+    the T3 time so that the whole text -> waveform job has a number (the reference's README reports the two times for its
+    run, README.md:150-153)."""
     import queue
     import threading
     from chatterbox_vllm_amd import cfm_weights as CW, flow_weights as FW, hift_weights as HW
@@ -395,28 +397,34 @@ def s3gen_job_leg(device, lengths, prompt_tokens=250, workers=(1, 3)):
            "prompt_feat": (2.0 * torch.randn(1, 2 * prompt_tokens, 80, generator=g) - 4.0).to(dev),
            "embedding": torch.randn(1, 192, generator=g).to(dev)}
     toks = [torch.randint(0, 6561, (n,), generator=g).to(dev) for n in lengths]
-    chains, streams, runs = [], [], {}
-    for nw in workers:
-        while len(chains) < nw:
-            chains.append(S3Token2Wav(flow_sd, hift_sd, max_tokens=prompt_tokens + max(lengths), device=device))
-            streams.append(torch.cuda.Stream(device=dev))
-            with torch.cuda.stream(streams[-1]):
-                chains[-1].inference(toks[0], ref)
+    order = sorted(range(len(toks)), key=lambda i: -lengths[i])
+    runs = []
+    for nw, nb in variants:
+        chains = [S3Token2Wav(flow_sd, hift_sd, max_tokens=prompt_tokens + max(lengths), device=device, max_batch=nb) for _ in range(nw)]
+        streams = [torch.cuda.Stream(device=dev) for _ in range(nw)]
+
+        def run_group(w, group):
+            if nb == 1:
+                return chains[w].inference(toks[group[0]], ref)[0].shape[1]
+            return sum(wav.shape[1] for wav in chains[w].inference_batch([toks[i] for i in group], ref))
+
+        for w in range(nw):
+            with torch.cuda.stream(streams[w]):
+                run_group(w, order[:nb])
         torch.cuda.synchronize(device)
         q = queue.Queue()
-        for i in sorted(range(len(toks)), key=lambda i: -lengths[i]):
-            q.put(i)
+        for j in range(0, len(order), nb):
+            q.put(order[j:j + nb])
         samples = [0] * nw
 
         def work(w):
             with torch.cuda.stream(streams[w]):
                 while True:
                     try:
-                        i = q.get_nowait()
+                        group = q.get_nowait()
                     except queue.Empty:
                         break
-                    wav, _ = chains[w].inference(toks[i], ref)
-                    samples[w] += wav.shape[1]
+                    samples[w] += run_group(w, group)
                 streams[w].synchronize()
 
         t0 = time.perf_counter()
@@ -426,16 +434,18 @@ def s3gen_job_leg(device, lengths, prompt_tokens=250, workers=(1, 3)):
         for t in threads:
             t.join()
         torch.cuda.synchronize(device)
-        runs[nw] = (time.perf_counter() - t0, sum(samples) / 24000)
-    for c in chains:
-        c.shutdown()
-    dt, audio = runs[workers[0]]
+        dt = time.perf_counter() - t0
+        for c in chains:
+            c.shutdown()
+        runs.append({"utterances_in_flight": nw, "utterances_per_call": nb, "seconds": round(dt, 3),
+                     "value": round(sum(samples) / 24000 / dt, 1), "audio_seconds": round(sum(samples) / 24000, 1)})
+    first = runs[0]
     rec = {"workload": f"S3Gen over the job's {len(lengths)} chunks ({sum(lengths)} speech tokens, {min(lengths)}-{max(lengths)} per chunk), "
                        f"{prompt_tokens}-token voice prompt, 10 Euler steps, seeded synthetic weights",
-           "metric": "generated audio seconds per second", "value": round(audio / dt, 1), "unit": "audio s/s",
-           "utterances_in_flight": workers[0], "seconds": round(dt, 3), "audio_seconds": round(audio, 1), "dtype": "f32"}
-    rec["in_flight"] = [{"utterances_in_flight": nw, "seconds": round(runs[nw][0], 3), "value": round(runs[nw][1] / runs[nw][0], 1)}
-                        for nw in workers[1:]]
+           "metric": "generated audio seconds per second", "value": first["value"], "unit": "audio s/s",
+           "utterances_in_flight": first["utterances_in_flight"], "utterances_per_call": first["utterances_per_call"],
+           "seconds": first["seconds"], "audio_seconds": first["audio_seconds"], "dtype": "f32"}
+    rec["variants"] = [{k: v for k, v in r.items() if k != "audio_seconds"} for r in runs[1:]]
     return rec
 
 

@@ -8,7 +8,7 @@ only."""
 from __future__ import annotations
 
 import ctypes as C
-from typing import Dict, Optional, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 
@@ -17,17 +17,21 @@ from .hift import HiftError, check, load, _P, _ptr, _stream_ptr
 
 _SIGNATURES = {
     "s3cfm_create": ([C.c_int32, C.c_int32, C.POINTER(_P)], C.c_int),
+    "s3cfm_create_batched": ([C.c_int32, C.c_int32, C.c_int32, C.POINTER(_P)], C.c_int),
     "s3cfm_destroy": ([_P], C.c_int),
     "s3cfm_load_tensor": ([_P, C.c_char_p, _P, C.POINTER(C.c_int64), C.c_int32], C.c_int),
     "s3cfm_finalize": ([_P], C.c_int),
     "s3cfm_estimator": ([_P, _P, _P, _P, _P, C.c_float, C.c_int32, _P, _P], C.c_int),
     "s3cfm_solve": ([_P, _P, _P, _P, _P, C.c_int32, C.POINTER(C.c_float), C.c_int32, C.c_double, _P, _P], C.c_int),
+    "s3cfm_solve_batch": ([_P, C.c_int32, C.POINTER(C.c_int32), C.c_int32, _P, _P, _P, _P, C.POINTER(C.c_float), C.c_int32, C.c_double, _P,
+                           _P], C.c_int),
     "s3cfm_op_linear": ([_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, C.c_int32,
                          _P, _P, C.c_int32, C.POINTER(C.c_float), _P], C.c_int),
-    "s3cfm_op_attention": ([_P, _P, C.c_int32, C.c_int32, _P, C.c_int32, C.POINTER(C.c_float), _P], C.c_int),
+    "s3cfm_op_attention": ([_P, _P, C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int32, _P, C.c_int32, C.POINTER(C.c_float), _P], C.c_int),
 }
 
 VT_LD = 576                  # row stride of the frame-major V tensor (512 channels + padding)
+MAX_BATCH = 8                # S3CFM_MAX_BATCH
 
 
 def _lib() -> C.CDLL:
@@ -47,18 +51,22 @@ class CausalConditionalCFM:
 
     ``rand_noise`` is the fixed noise the reference draws once at construction (``torch.randn([1, 80, 50 * 300])``,
     flow_matching.py:201) and slices per utterance; it is drawn the same way here, from torch's global CPU generator
-    unless one is passed."""
+    unless one is passed.
+
+    ``max_batch`` > 1 gives the workspace room for that many utterances per ``forward_batch`` call (no counterpart in the
+    reference, which runs one utterance per call)."""
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], max_frames: int = 3000, device: int = 0,
-                 inference_cfg_rate: float = CW.CFG_RATE, generator: Optional[torch.Generator] = None):
+                 inference_cfg_rate: float = CW.CFG_RATE, generator: Optional[torch.Generator] = None, max_batch: int = 1):
         self._lib = _lib()
         self.device = torch.device("cuda", device)
         self.max_frames = max_frames
+        self.max_batch = max_batch
         self.inference_cfg_rate = inference_cfg_rate
         self.rand_noise = torch.randn([1, CW.MEL, CW.NOISE_FRAMES], generator=generator)
         self._noise_dev = None
         h = _P()
-        check(self._lib, self._lib.s3cfm_create(device, max_frames, C.byref(h)))
+        check(self._lib, self._lib.s3cfm_create_batched(device, max_frames, max_batch, C.byref(h)))
         self._h = h
         try:
             for name, _ in CW.tensor_inventory():
@@ -117,6 +125,49 @@ class CausalConditionalCFM:
 
     __call__ = forward
 
+    def solve_euler_batch(self, z: torch.Tensor, t_span: torch.Tensor, mu: torch.Tensor, spks: torch.Tensor, cond: torch.Tensor,
+                          frames: Sequence[int]) -> torch.Tensor:
+        """``solve_euler`` for n utterances in shared launches: z, mu, cond [n, 80, L] (zeros from ``frames[u]`` on), spks
+        [n, 80] -> [n, 80, L]; columns of row u from ``frames[u]`` on are unspecified."""
+        f = lambda a: a.to(self.device, torch.float32).contiguous()
+        z, mu, spks, cond = f(z), f(mu), f(spks), f(cond)
+        n, L = mu.shape[0], mu.shape[2]
+        self._check_len(L)
+        if n < 1 or n > self.max_batch:
+            raise ValueError(f"{n} utterances exceed the workspace ({self.max_batch})")
+        assert mu.shape == (n, CW.MEL, L) and z.shape == mu.shape and cond.shape == mu.shape and spks.shape == (n, CW.MEL)
+        assert len(frames) == n and all(1 <= int(v) <= L for v in frames)
+        ts = t_span.detach().to("cpu", torch.float32).contiguous()
+        steps = ts.numel() - 1
+        grid = (C.c_float * (steps + 1))(*ts.tolist())
+        lens = (C.c_int32 * n)(*[int(v) for v in frames])
+        mel = torch.empty_like(mu)
+        check(self._lib, self._lib.s3cfm_solve_batch(self._h, n, lens, L, _ptr(mu), _ptr(spks), _ptr(cond), _ptr(z), grid, steps,
+                                                     float(self.inference_cfg_rate), _ptr(mel), _stream_ptr(self.device)))
+        return mel
+
+    @torch.inference_mode()
+    def forward_batch(self, mu: Sequence[torch.Tensor], spks: Sequence[torch.Tensor], cond: Sequence[torch.Tensor], n_timesteps: int = 10,
+                      temperature: float = 1.0) -> List[torch.Tensor]:
+        """``forward`` for several utterances at once: lists of mu [1, 80, L_u], spks [1, 80], cond [1, 80, L_u] -> list of mel
+        [1, 80, L_u].  Every utterance takes the leading columns of ``rand_noise``, as its own ``forward`` call would."""
+        n = len(mu)
+        frames = [int(m.shape[2]) for m in mu]
+        L = max(frames)
+        if L > self.rand_noise.shape[2]:
+            raise ValueError(f"{L} mel frames exceed the fixed noise buffer ({self.rand_noise.shape[2]})")
+        if self._noise_dev is None:
+            self._noise_dev = self.rand_noise.to(self.device)
+        mu_b = torch.zeros(n, CW.MEL, L, dtype=torch.float32, device=self.device)
+        cond_b, z_b = torch.zeros_like(mu_b), torch.zeros_like(mu_b)
+        for u in range(n):
+            mu_b[u, :, :frames[u]] = mu[u][0]
+            cond_b[u, :, :frames[u]] = cond[u][0]
+            z_b[u, :, :frames[u]] = self._noise_dev[0, :, :frames[u]] * temperature
+        spks_b = torch.cat([s.to(self.device, torch.float32) for s in spks], dim=0)
+        mel = self.solve_euler_batch(z_b, CW.t_span(n_timesteps), mu_b, spks_b, cond_b, frames)
+        return [mel[u:u + 1, :, :frames[u]] for u in range(n)]
+
     def shutdown(self) -> None:
         if getattr(self, "_h", None):
             self._lib.s3cfm_destroy(self._h)
@@ -157,21 +208,24 @@ def linear_op(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, pad: int = 0
     return y_full[:, :, :L], (None if vt_full is None else vt_full[:, :L, :512]), us.value
 
 
-def attention_op(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, iters: int = 0):
-    """``s3cfm_op_attention`` on q, k, v [2, 512, L] (channel-major, head h in channels 64 h ..): returns (o [2, 512, L],
-    average microseconds of `iters` launches)."""
+def attention_op(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, iters: int = 0, keys: Optional[Sequence[int]] = None):
+    """``s3cfm_op_attention`` on q, k, v [2 n, 512, L] (channel-major, head h in channels 64 h ..; rows 2 u and 2 u + 1 belong
+    to utterance u, whose first ``keys[u]`` frames are real): returns (o [2 n, 512, L], average microseconds of `iters`
+    launches)."""
     lib = _lib()
-    L = q.shape[2]
+    L, rows = q.shape[2], q.shape[0]
+    assert rows % 2 == 0 and rows // 2 <= MAX_BATCH
     ld = (L + 63) // 64 * 64
     if (ld // 64) % 2 == 0:
         ld += 64
     dev = q.device
-    qk = torch.zeros(2, 1024, ld, dtype=torch.float32, device=dev)
+    qk = torch.zeros(rows, 1024, ld, dtype=torch.float32, device=dev)
     qk[:, :512, :L] = q
     qk[:, 512:, :L] = k
-    vt = torch.zeros(2, ld, VT_LD, dtype=torch.float32, device=dev)
+    vt = torch.zeros(rows, ld, VT_LD, dtype=torch.float32, device=dev)
     vt[:, :L, :512] = v.transpose(1, 2)
-    o = torch.zeros(2, 512, ld, dtype=torch.float32, device=dev)
+    o = torch.zeros(rows, 512, ld, dtype=torch.float32, device=dev)
     us = C.c_float(0)
-    check(lib, lib.s3cfm_op_attention(_ptr(qk), _ptr(vt), L, ld, _ptr(o), iters, C.byref(us), _stream_ptr(dev)))
+    lens = None if keys is None else (C.c_int32 * (rows // 2))(*[int(v) for v in keys])
+    check(lib, lib.s3cfm_op_attention(_ptr(qk), _ptr(vt), rows // 2, lens, L, ld, _ptr(o), iters, C.byref(us), _stream_ptr(dev)))
     return o[:, :, :L], us.value

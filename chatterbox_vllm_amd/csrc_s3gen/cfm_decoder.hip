@@ -21,7 +21,7 @@
 namespace {
 
 constexpr int kMel = S3CFM_MEL, kIn = 4 * S3CFM_MEL, kC = 256, kTime = 1024, kHeads = 8, kInner = 512, kFf = 1024;
-constexpr int kBlocks = 4, kMid = 12, kStages = kMid + 2, kRows = 2;
+constexpr int kBlocks = 4, kMid = 12, kStages = kMid + 2, kRows = 2, kMaxUtt = 8;
 // Row strides are odd multiples of 256 bytes: a tile's rows (64 channels of K, 32 frames of V) then spread over the L2
 // channels instead of landing on one or two of them, which strides of 2 or 4 KiB would do.
 constexpr int kVtLd = kInner + 64;
@@ -142,7 +142,10 @@ struct AttnArgs {
     const float* q; const float* k; size_t qk_bs; int ld;     // [row][512][ld] channel-major, head h at channels 64 h ..
     const float* vt; size_t vt_bs;                            // [row][L][kVtLd] frame-major
     float* o; size_t o_bs;                                    // [row][512][ld]
-    int L;
+    int L;                                                    // queries per row
+    int rows;                                                 // rows in the launch (two per utterance: with and without conditioning)
+    int Lk[kMaxUtt];                                          // keys of rows 2 u and 2 u + 1 (an utterance shorter than L: its
+                                                              //   frames past Lk[u] are padding that no query may see)
 };
 // QT: 32-query tiles per wave (1 to 3).  With more tiles every K and V value a wave loads feeds more matrix work and the
 // wave has more independent accumulators in flight (QT = 2 runs a tile 25 % faster than QT = 1); the launcher picks the QT
@@ -152,10 +155,20 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
     __shared__ float so[4 * 32 * 64];
     __shared__ float sm[4][64], sl[4][64];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), half = lane >> 5, col = lane & 31;
-    // workgroup i runs on XCD i % 8: give each XCD two of the sixteen (row, head) pairs, so that the K and V it streams
+    // workgroup i runs on XCD i % 8: give each XCD its own share of the (row, head) pairs, so that the K and V it streams
     // (0.5 KiB per frame and pair) stay in its own L2
-    const int pair = (blockIdx.x & 7) * 2 + ((blockIdx.x >> 3) & 1), qt = blockIdx.x >> 4;
+    const int npairs = a.rows * kHeads, p = blockIdx.x % npairs, qt = blockIdx.x / npairs;
+    const int pair = (p & 7) * a.rows + (p >> 3);
     const int b = pair >> 3, h = pair & 7;
+    const int Lk = a.Lk[b >> 1];
+    if (qt * QT * 32 >= Lk) {
+        // queries that are all padding: zeros keep what follows finite without the work
+        for (int i = tid; i < 64 * QT * 32; i += 256) {
+            const int qn = qt * QT * 32 + i % (QT * 32);
+            if (qn < a.L) a.o[b * a.o_bs + (size_t)(h * 64 + i / (QT * 32)) * a.ld + qn] = 0.f;
+        }
+        return;
+    }
     float Q[QT][32];
 #pragma unroll
     for (int u = 0; u < QT; ++u) {
@@ -179,7 +192,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
     const __amdgpu_buffer_rsrc_t vr_ = make_rsrc(a.vt + b * a.vt_bs + h * 64, (unsigned)a.ld * kVtLd * 4u);
     const unsigned klane = (unsigned)(half * a.ld + col) * 4u, vlane = (unsigned)(4 * half * kVtLd + col) * 4u;
     const unsigned krow2 = (unsigned)a.ld * 8u;                // bytes between channels 2 kk and 2 kk + 2
-    const int ntiles = (a.L + 31) / 32;
+    const int ntiles = (Lk + 31) / 32;
     // A tile's 32 K loads are issued a whole tile ahead (right after the score products that free their registers), its 32 V
     // loads before the score products; the scheduling barriers keep the compiler from sinking each load next to its use,
     // which would leave one load in flight at a time.
@@ -214,10 +227,10 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
         // ln 2 (the factor sits in Q), so the exponentials below are single v_exp_f32 instructions
 #pragma unroll
         for (int u = 0; u < QT; ++u) {
-            if (key0 + 32 > a.L) {
+            if (key0 + 32 > Lk) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    if (key0 + 8 * (r >> 2) + 4 * half + (r & 3) >= a.L) s[u][r] = -INFINITY;
+                    if (key0 + 8 * (r >> 2) + 4 * half + (r & 3) >= Lk) s[u][r] = -INFINITY;
             }
             float mx = s[u][0];
 #pragma unroll
@@ -452,17 +465,17 @@ __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void lin_kernel(LinArgs a)
 }
 
 // The estimator's input (decoder.py:254-260): rows 0..79 x, 80..159 mu, 160..239 the speaker vector on every frame,
-// 240..319 cond.  uncond_row1: row 1 is the unconditioned call of solve_euler (flow_matching.py:105-118): the same x, zeros
-// for the rest; otherwise the four inputs hold two rows each.
+// 240..319 cond.  uncond_odd: rows 2 u and 2 u + 1 are the two calls of solve_euler for utterance u (flow_matching.py:105-118):
+// the odd row takes the same x and zeros for the rest; otherwise the four inputs hold one row per row of the launch.
 __global__ void pack_input_kernel(const float* __restrict__ x, const float* __restrict__ mu, const float* __restrict__ spks,
-                                  const float* __restrict__ cond, int L, int uncond_row1, float* __restrict__ in, int ld) {
+                                  const float* __restrict__ cond, int L, int uncond_odd, float* __restrict__ in, int ld) {
     const int t = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y, r = blockIdx.z;
     if (t >= L) return;
     const int part = c / kMel, cc = c % kMel;
-    const int src_row = uncond_row1 ? 0 : r;
+    const int src_row = uncond_odd ? r >> 1 : r;
     float v;
     if (part == 0) v = x[((size_t)src_row * kMel + cc) * L + t];
-    else if (uncond_row1 && r == 1) v = 0.f;
+    else if (uncond_odd && (r & 1)) v = 0.f;
     else if (part == 1) v = mu[((size_t)src_row * kMel + cc) * L + t];
     else if (part == 2) v = spks[src_row * kMel + cc];
     else v = cond[((size_t)src_row * kMel + cc) * L + t];
@@ -470,21 +483,24 @@ __global__ void pack_input_kernel(const float* __restrict__ x, const float* __re
 }
 
 // One Euler step with classifier-free guidance (flow_matching.py:125-127): x += dt * ((1 + rate) d[0] - rate d[1]), written
-// to the x rows of both estimator inputs and, when mel is not null, to the caller's [80][L] output.  Each product and sum
-// is rounded on its own, as the reference's separate tensor operations are.
+// to the x rows of both estimator inputs and, when mel is not null, to the caller's [80][L] output; blockIdx.z is the
+// utterance (rows 2 z and 2 z + 1).  Each product and sum is rounded on its own, as the reference's separate tensor
+// operations are.
 __global__ void euler_step_kernel(const float* __restrict__ d, size_t d_bs, float* __restrict__ in, size_t in_bs, int ld, int L, float dt,
                                   float one_plus_rate, float rate, float* __restrict__ mel) {
 #pragma clang fp contract(off)
-    const int t = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
+    const int t = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y, u = blockIdx.z;
     if (t >= L) return;
     const size_t o = (size_t)c * ld + t;
+    d += 2 * u * d_bs;
+    in += 2 * u * in_bs;
     const float a = one_plus_rate * d[o], b = rate * d[d_bs + o];      // plain operators: the pragma above binds them
     const float g = a - b;
     const float p = dt * g;
     const float xn = in[o] + p;
     in[o] = xn;
     in[in_bs + o] = xn;
-    if (mel) mel[(size_t)c * L + t] = xn;
+    if (mel) mel[((size_t)u * kMel + c) * L + t] = xn;
 }
 
 __global__ void copy_rows_kernel(const float* __restrict__ src, size_t src_bs, float* __restrict__ dst, size_t dst_bs, int ld, int L) {
@@ -509,7 +525,9 @@ struct Stage { Resnet res; Transformer tf[kBlocks]; Lin tail; bool has_tail = fa
 }  // namespace
 
 struct s3cfm {
-    int device = 0, max_frames = 0, ld = 0;
+    int device = 0, max_frames = 0, ld = 0, max_batch = 1;
+    int rows = kRows;                                          // rows of the running call: two per utterance
+    int Lk[kMaxUtt] = {};                                      // frames of each utterance of the running call
     bool finalized = false;
     std::map<std::string, Host> raw;
     std::vector<void*> owned;
@@ -642,13 +660,13 @@ int launch_attn(const AttnArgs& a, hipStream_t st) {
     int best = 1;
     double best_cost = 1e30;
     for (int qt = 1; qt <= 3; ++qt) {                          // four tiles per wave would spill registers
-        const long long wgs = (long long)((tiles + qt - 1) / qt) * kRows * kHeads;
+        const long long wgs = (long long)((tiles + qt - 1) / qt) * a.rows * kHeads;
         const double per_tile = qt == 1 ? 1.02 : 1.0;           // measured: one tile per wave is a few per cent slower per tile
         const double cost = (double)((wgs + 255) / 256) * qt * per_tile;
         if (cost < best_cost - 1e-9) { best_cost = cost; best = qt; }
     }
     if (force >= 1 && force <= 3) best = force;
-    const dim3 grid((tiles + best - 1) / best * kRows * kHeads);
+    const dim3 grid((tiles + best - 1) / best * a.rows * kHeads);
     if (best == 1) hipLaunchKernelGGL(attn_kernel<1>, grid, dim3(256), 0, st, a);
     else if (best == 2) hipLaunchKernelGGL(attn_kernel<2>, grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL(attn_kernel<3>, grid, dim3(256), 0, st, a);
@@ -667,11 +685,11 @@ int run_lin(const s3cfm* h, const Lin& l, const float* x, int x_rows, float* y, 
     a.yt = yt; a.yt_bs = (size_t)h->ld * kVtLd; a.yt_ld = kVtLd; a.yt_from = yt_from;
     a.Cin = l.Cin; a.Cout = l.Cout; a.CoutPad = (l.Cout + 31) / 32 * 32; a.K = l.K; a.pad = pad; a.L = L;
     a.rsum = rsum; a.ln_eps = 1e-5f;
-    return launch_lin(a, out_act, kRows, st);
+    return launch_lin(a, out_act, h->rows, st);
 }
 
 int run_ln(const s3cfm* h, int mode, const float* x, float* y, int L, const Norm& n, const float* add, hipStream_t st) {
-    const dim3 grid((L + 7) / 8, kRows);
+    const dim3 grid((L + 7) / 8, h->rows);
     const size_t bs = (size_t)kC * h->ld;
     if (mode == LN_PLAIN) hipLaunchKernelGGL(ln256_kernel<LN_PLAIN>, grid, dim3(256), 0, st, x, y, h->ld, bs, L, n.g, n.b, add);
     else if (mode == LN_MISH) hipLaunchKernelGGL(ln256_kernel<LN_MISH>, grid, dim3(256), 0, st, x, y, h->ld, bs, L, n.g, n.b, add);
@@ -695,7 +713,8 @@ int run_transformer(s3cfm* h, const Transformer& b, int L, hipStream_t st) {
     const int ld = h->ld;
     // norm1 rides in the q/k/v projection (LinArgs::rsum); q and k channel-major into QK, v frame-major into VT
     if (run_lin(h, b.qkv, h->X, kC, h->QK, 2 * kInner, L, 0, OUT_NONE, nullptr, st, h->VT, 2 * kInner, b.qkv_rsum)) return 1;
-    AttnArgs at{h->QK, h->QK + (size_t)kInner * ld, (size_t)2 * kInner * ld, ld, h->VT, (size_t)ld * kVtLd, h->O, (size_t)kInner * ld, L};
+    AttnArgs at{h->QK, h->QK + (size_t)kInner * ld, (size_t)2 * kInner * ld, ld, h->VT, (size_t)ld * kVtLd, h->O, (size_t)kInner * ld, L, h->rows, {}};
+    for (int u = 0; u < kMaxUtt; ++u) at.Lk[u] = h->Lk[u];
     if (launch_attn(at, st)) return 1;
     if (run_lin(h, b.out, h->O, kInner, h->X, kC, L, 0, OUT_NONE, h->X, st)) return 1;
     // norm3 rides in the first feed-forward layer
@@ -703,14 +722,14 @@ int run_transformer(s3cfm* h, const Transformer& b, int L, hipStream_t st) {
     return run_lin(h, b.w2, h->H, kFf, h->X, kC, L, 0, OUT_NONE, h->X, st);
 }
 
-int copy_rows(const float* src, int src_rows, float* dst, int dst_rows, int ld, int L, hipStream_t st) {
-    hipLaunchKernelGGL(copy_rows_kernel, dim3((L + 255) / 256, kC, kRows), dim3(256), 0, st, src, (size_t)src_rows * ld, dst,
+int copy_rows(const float* src, int src_rows, float* dst, int dst_rows, int ld, int L, int rows, hipStream_t st) {
+    hipLaunchKernelGGL(copy_rows_kernel, dim3((L + 255) / 256, kC, rows), dim3(256), 0, st, src, (size_t)src_rows * ld, dst,
                        (size_t)dst_rows * ld, ld, L);
     S3_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
-// ConditionalDecoder.forward (decoder.py:233-317) on IN [2][320][L] at time t -> D [2][80][L]
+// ConditionalDecoder.forward (decoder.py:233-317) on IN [rows][320][L] at time t -> D [rows][80][L]; h->rows and h->Lk are set by the caller
 int run_estimator(s3cfm* h, float t, int L, hipStream_t st) {
     // time embedding and its 14 per-stage projections (decoder.py:251-252, matcha/decoder.py:58)
     hipLaunchKernelGGL(sin_emb_kernel, dim3(1), dim3(192), 0, st, t, h->freq, h->emb);
@@ -730,11 +749,11 @@ int run_estimator(s3cfm* h, float t, int L, hipStream_t st) {
             if (run_transformer(h, sg.tf[j], L, st)) return 1;
         if (s == 0) {
             // the skip connection (decoder.py:278), then the stage's trailing causal convolution
-            if (copy_rows(h->X, kC, h->CAT + (size_t)kC * ld, 2 * kC, ld, L, st)) return 1;
+            if (copy_rows(h->X, kC, h->CAT + (size_t)kC * ld, 2 * kC, ld, L, h->rows, st)) return 1;
             if (run_lin(h, sg.tail, h->X, kC, h->Y, kC, L, 2, OUT_NONE, nullptr, st)) return 1;
             std::swap(h->X, h->Y);
         } else if (s == kStages - 2) {
-            if (copy_rows(h->X, kC, h->CAT, 2 * kC, ld, L, st)) return 1;        // decoder.py:301
+            if (copy_rows(h->X, kC, h->CAT, 2 * kC, ld, L, h->rows, st)) return 1;        // decoder.py:301
         } else if (s == kStages - 1) {
             if (run_lin(h, sg.tail, h->X, kC, h->Y, kC, L, 2, OUT_NONE, nullptr, st)) return 1;
             std::swap(h->X, h->Y);
@@ -748,16 +767,18 @@ int run_estimator(s3cfm* h, float t, int L, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int s3cfm_create(int32_t device, int32_t max_frames, s3cfm** out) {
-    S3_REQUIRE(out && max_frames >= 1 && max_frames <= S3CFM_MAX_FRAMES, "bad arguments");
+extern "C" int s3cfm_create_batched(int32_t device, int32_t max_frames, int32_t max_batch, s3cfm** out) {
+    S3_REQUIRE(out && max_frames >= 1 && max_frames <= S3CFM_MAX_FRAMES && max_batch >= 1 && max_batch <= S3CFM_MAX_BATCH, "bad arguments");
     S3_HIP_CHECK(hipSetDevice(device));
     s3cfm* h = new s3cfm();
-    h->device = device; h->max_frames = max_frames;
+    h->device = device; h->max_frames = max_frames; h->max_batch = max_batch;
     h->ld = (max_frames + 63) / 64 * 64;
     if ((h->ld / 64) % 2 == 0) h->ld += 64;
     *out = h;
     return 0;
 }
+
+extern "C" int s3cfm_create(int32_t device, int32_t max_frames, s3cfm** out) { return s3cfm_create_batched(device, max_frames, 1, out); }
 
 extern "C" int s3cfm_destroy(s3cfm* h) {
     if (!h) return 0;
@@ -833,15 +854,16 @@ extern "C" int s3cfm_finalize(s3cfm* h) {
     if (upload(h, &h->freq, freq.data(), freq.size())) return 1;
     const size_t ld = h->ld;
     if (dalloc(h, &h->emb, kIn) || dalloc(h, &h->th, kTime) || dalloc(h, &h->temb, kTime) || dalloc(h, &h->tvec, kStages * kC)) return 1;
-    if (dalloc(h, &h->IN, kRows * kIn * ld) || dalloc(h, &h->CAT, kRows * 2 * kC * ld) || dalloc(h, &h->D, kRows * kMel * ld)) return 1;
+    const size_t mr = (size_t)kRows * h->max_batch;
+    if (dalloc(h, &h->IN, mr * kIn * ld) || dalloc(h, &h->CAT, mr * 2 * kC * ld) || dalloc(h, &h->D, mr * kMel * ld)) return 1;
     for (float** p : {&h->X, &h->Y, &h->Z})
-        if (dalloc(h, p, kRows * kC * ld)) return 1;
-    if (dalloc(h, &h->QK, kRows * 2 * kInner * ld) || dalloc(h, &h->VT, kRows * kVtLd * ld) || dalloc(h, &h->O, kRows * kInner * ld) ||
-        dalloc(h, &h->H, kRows * kFf * ld))
+        if (dalloc(h, p, mr * kC * ld)) return 1;
+    if (dalloc(h, &h->QK, mr * 2 * kInner * ld) || dalloc(h, &h->VT, mr * kVtLd * ld) || dalloc(h, &h->O, mr * kInner * ld) ||
+        dalloc(h, &h->H, mr * kFf * ld))
         return 1;
     // the attention kernel reads K and V up to the end of a 32-frame tile: what lies past an utterance must be finite
-    S3_HIP_CHECK(hipMemset(h->QK, 0, kRows * 2 * kInner * ld * sizeof(float)));
-    S3_HIP_CHECK(hipMemset(h->VT, 0, kRows * kVtLd * ld * sizeof(float)));
+    S3_HIP_CHECK(hipMemset(h->QK, 0, mr * 2 * kInner * ld * sizeof(float)));
+    S3_HIP_CHECK(hipMemset(h->VT, 0, mr * kVtLd * ld * sizeof(float)));
     S3_HIP_CHECK(hipDeviceSynchronize());
     h->raw.clear();
     h->finalized = true;
@@ -855,6 +877,8 @@ extern "C" int s3cfm_estimator(s3cfm* h, const float* x_dev, const float* mu_dev
                "bad arguments or more frames than the workspace holds");
     S3_HIP_CHECK(hipSetDevice(h->device));
     hipStream_t st = static_cast<hipStream_t>(stream);
+    h->rows = kRows;
+    h->Lk[0] = L;
     hipLaunchKernelGGL(pack_input_kernel, dim3((L + 255) / 256, kIn, kRows), dim3(256), 0, st, x_dev, mu_dev, spks_dev, cond_dev, L, 0, h->IN,
                        h->ld);
     S3_HIP_CHECK(hipGetLastError());
@@ -864,30 +888,44 @@ extern "C" int s3cfm_estimator(s3cfm* h, const float* x_dev, const float* mu_dev
     return 0;
 }
 
-extern "C" int s3cfm_solve(s3cfm* h, const float* mu_dev, const float* spks_dev, const float* cond_dev, const float* noise_dev, int32_t L,
-                           const float* t_span, int32_t n_timesteps, double cfg_rate, float* mel_dev, void* stream) {
+extern "C" int s3cfm_solve_batch(s3cfm* h, int32_t n_utt, const int32_t* frames, int32_t L, const float* mu_dev, const float* spks_dev,
+                                 const float* cond_dev, const float* noise_dev, const float* t_span, int32_t n_timesteps, double cfg_rate,
+                                 float* mel_dev, void* stream) {
     S3_REQUIRE(h && h->finalized, "handle not finalized");
-    S3_REQUIRE(mu_dev && spks_dev && cond_dev && noise_dev && mel_dev && t_span && L >= 1 && L <= h->max_frames,
+    S3_REQUIRE(n_utt >= 1 && n_utt <= h->max_batch, "more utterances than the workspace holds");
+    S3_REQUIRE(frames && mu_dev && spks_dev && cond_dev && noise_dev && mel_dev && t_span && L >= 1 && L <= h->max_frames,
                "bad arguments or more frames than the workspace holds");
+    for (int u = 0; u < n_utt; ++u) S3_REQUIRE(frames[u] >= 1 && frames[u] <= L, "an utterance's frames must lie in [1, L]");
     S3_REQUIRE(n_timesteps >= 1 && n_timesteps <= 1000, "bad number of steps");
     for (int i = 0; i <= n_timesteps; ++i) S3_REQUIRE(std::isfinite(t_span[i]), "time grid holds a value that is not finite");
     S3_HIP_CHECK(hipSetDevice(h->device));
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(pack_input_kernel, dim3((L + 255) / 256, kIn, kRows), dim3(256), 0, st, noise_dev, mu_dev, spks_dev, cond_dev, L, 1, h->IN,
-                       h->ld);
+    // Every layer but attention works frame by frame or looks back in time only, so utterances of different lengths share
+    // the launches at the longest one's L: what is computed past an utterance's end stays finite and is never read by its
+    // valid frames; attention gets each utterance's own key count.
+    h->rows = kRows * n_utt;
+    for (int u = 0; u < n_utt; ++u) h->Lk[u] = frames[u];
+    hipLaunchKernelGGL(pack_input_kernel, dim3((L + 255) / 256, kIn, h->rows), dim3(256), 0, st, noise_dev, mu_dev, spks_dev, cond_dev, L, 1,
+                       h->IN, h->ld);
     S3_HIP_CHECK(hipGetLastError());
     // the guidance factors are Python doubles in the reference (1.0 + 0.7 and 0.7), rounded to fp32 when they meet a tensor
     // flow_matching.py:97-131: t and dt advance in fp32, each difference taken against the running t
     float t = t_span[0], dt = t_span[1] - t_span[0];
     for (int step = 1; step <= n_timesteps; ++step) {
         if (run_estimator(h, t, L, st)) return 1;
-        hipLaunchKernelGGL(euler_step_kernel, dim3((L + 255) / 256, kMel), dim3(256), 0, st, h->D, (size_t)kMel * h->ld, h->IN,
+        hipLaunchKernelGGL(euler_step_kernel, dim3((L + 255) / 256, kMel, n_utt), dim3(256), 0, st, h->D, (size_t)kMel * h->ld, h->IN,
                            (size_t)kIn * h->ld, h->ld, L, dt, (float)(1.0 + cfg_rate), (float)cfg_rate, step == n_timesteps ? mel_dev : nullptr);
         S3_HIP_CHECK(hipGetLastError());
         t = t + dt;
         if (step < n_timesteps) dt = t_span[step + 1] - t;
     }
     return 0;
+}
+
+extern "C" int s3cfm_solve(s3cfm* h, const float* mu_dev, const float* spks_dev, const float* cond_dev, const float* noise_dev, int32_t L,
+                           const float* t_span, int32_t n_timesteps, double cfg_rate, float* mel_dev, void* stream) {
+    const int32_t frames = L;
+    return s3cfm_solve_batch(h, 1, &frames, L, mu_dev, spks_dev, cond_dev, noise_dev, t_span, n_timesteps, cfg_rate, mel_dev, stream);
 }
 
 // ---- single operations, for tests and timing --------------------------------------------------------------------------
@@ -956,11 +994,17 @@ extern "C" int s3cfm_op_linear(const float* x_dev, int32_t Cin, int32_t L, int32
     return rc;
 }
 
-extern "C" int s3cfm_op_attention(const float* qk_dev, const float* vt_dev, int32_t L, int32_t ld, float* o_dev, int32_t iters, float* avg_us,
-                                  void* stream) {
+extern "C" int s3cfm_op_attention(const float* qk_dev, const float* vt_dev, int32_t n_utt, const int32_t* keys, int32_t L, int32_t ld,
+                                  float* o_dev, int32_t iters, float* avg_us, void* stream) {
     S3_REQUIRE(qk_dev && vt_dev && o_dev && L >= 1 && ld >= (L + 31) / 32 * 32 && iters >= 0, "bad arguments (ld must cover whole 32-frame tiles)");
+    S3_REQUIRE(n_utt >= 1 && n_utt <= kMaxUtt, "bad number of utterances");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    AttnArgs at{qk_dev, qk_dev + (size_t)kInner * ld, (size_t)2 * kInner * ld, ld, vt_dev, (size_t)ld * kVtLd, o_dev, (size_t)kInner * ld, L};
+    AttnArgs at{qk_dev, qk_dev + (size_t)kInner * ld, (size_t)2 * kInner * ld, ld, vt_dev, (size_t)ld * kVtLd, o_dev, (size_t)kInner * ld, L,
+                kRows * n_utt, {}};
+    for (int u = 0; u < n_utt; ++u) {
+        at.Lk[u] = keys ? keys[u] : L;
+        S3_REQUIRE(at.Lk[u] >= 1 && at.Lk[u] <= L, "an utterance's keys must lie in [1, L]");
+    }
     const int rc = time_launches(iters, st, avg_us, [&]() { return launch_attn(at, st); });
     S3_HIP_CHECK(hipStreamSynchronize(st));
     return rc;

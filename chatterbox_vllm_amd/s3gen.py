@@ -8,10 +8,14 @@ reference dict (``ref_dict``, the "prod API" of s3gen.py:176-186, as ``Chatterbo
 ``decoder`` may replace the flow-matching stage by any callable with the reference decoder's call signature
 (flow.py:279-285): ``decoder(mu=[1, 80, L], mask=[1, 1, L], spks=[1, 80], cond=[1, 80, L], n_timesteps=int) ->
 (mel [1, 80, L], _)``, e.g. the reference's own ``s3gen.flow.decoder`` where its libraries are installed.  The default is this
-package's ``CausalConditionalCFM`` (cfm_decoder.py), built from the ``decoder.estimator.*`` entries of the flow state dict."""
+package's ``CausalConditionalCFM`` (cfm_decoder.py), built from the ``decoder.estimator.*`` entries of the flow state dict.
+
+``inference_batch`` takes several utterances of one voice through the flow-matching stage in shared kernel launches (the
+reference runs them one after the other, tts.py:489-493 inside its loop over the batch): the stage's launches are small for
+one short utterance, and several utterances together fill the GPU."""
 from __future__ import annotations
 
-from typing import Callable, Dict, Optional, Tuple
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import torch
 
@@ -24,12 +28,14 @@ S3GEN_SR = 24000
 
 class S3Token2Wav:
     def __init__(self, flow_state_dict: Dict[str, torch.Tensor], mel2wav_state_dict: Dict[str, torch.Tensor],
-                 decoder: Optional[Callable] = None, max_tokens: int = 1500, device: int = 0):
+                 decoder: Optional[Callable] = None, max_tokens: int = 1500, device: int = 0, max_batch: int = 1):
         self.device = torch.device("cuda", device)
         self.encoder = FlowEncoder(flow_state_dict, max_tokens=max_tokens, device=device)
         self.mel2wav = HiFTGenerator(mel2wav_state_dict, max_batch=1, max_frames=2 * max_tokens, device=device)
         self._own_decoder = decoder is None
-        self.decoder = CausalConditionalCFM(flow_state_dict, max_frames=2 * max_tokens, device=device) if decoder is None else decoder
+        self.decoder = (CausalConditionalCFM(flow_state_dict, max_frames=2 * max_tokens, device=device, max_batch=max_batch)
+                        if decoder is None else decoder)
+        self.max_batch = max_batch
         # silence the first 20 ms and fade in over the next 20 ms (s3gen.py:247-251)
         n_trim = S3GEN_SR // 50
         fade = torch.zeros(2 * n_trim)
@@ -63,6 +69,28 @@ class S3Token2Wav:
             n = min(wav.shape[1], self.trim_fade.numel())
             wav[:, :n] *= self.trim_fade[:n]
         return wav, src
+
+    @torch.inference_mode()
+    def inference_batch(self, speech_tokens: Sequence[torch.Tensor], ref_dict: dict, no_trim: bool = False, n_timesteps: int = 10,
+                        seed: int = 0) -> List[torch.Tensor]:
+        """``inference`` for several utterances of one voice (at most ``max_batch``): list of waveforms [1, 480 * 2 T_u].
+        Needs this package's decoder (``forward_batch``)."""
+        if not hasattr(self.decoder, "forward_batch"):
+            raise TypeError("the decoder in use has no forward_batch: call inference per utterance")
+        ins = []
+        for tok in speech_tokens:
+            tok = tok.unsqueeze(0) if tok.dim() == 1 else tok
+            ins.append(self.encoder.decoder_inputs(tok, ref_dict["prompt_token"], ref_dict["prompt_feat"], ref_dict["embedding"]))
+        mels = self.decoder.forward_batch([d["mu"] for d in ins], [d["spks"] for d in ins], [d["cond"] for d in ins],
+                                          n_timesteps=n_timesteps)
+        wavs = []
+        for d, mel in zip(ins, mels):
+            wav, _ = self.hift_inference(mel[:, :, d["prompt_len"]:].float().contiguous(), None, seed=seed)
+            if not no_trim:
+                n = min(wav.shape[1], self.trim_fade.numel())
+                wav[:, :n] *= self.trim_fade[:n]
+            wavs.append(wav)
+        return wavs
 
     def shutdown(self) -> None:
         self.encoder.shutdown()

@@ -7,7 +7,8 @@
  * estimator it calls twice per step, `ConditionalDecoder.forward` (decoder.py:233-317; built by s3gen.py:76-87 with 320 input
  * rows, 256 channels, one down stage, twelve mid stages, one up stage, four transformer blocks of 8 heads x 64 per stage).
  * One utterance per call (the reference asserts batch 1, flow.py:256), all masks ones, full attention
- * (`static_chunk_size` is 0, decoder.py:135).  All arithmetic is fp32, as in the reference.
+ * (`static_chunk_size` is 0, decoder.py:135); s3cfm_solve_batch runs several such calls in shared launches.  All arithmetic is
+ * fp32, as in the reference.
  *
  * Plain pointers and sizes only.  *_dev pointers are device memory on the handle's GPU; every function returns 0 on
  * success, s3hift_last_error() (s3hift_hip.h) describes a failure.  Calls on one handle must not overlap.  Kernels are
@@ -21,11 +22,15 @@ extern "C" {
 
 #define S3CFM_MEL 80
 #define S3CFM_MAX_FRAMES 15000
+#define S3CFM_MAX_BATCH 8
 
 typedef struct s3cfm s3cfm;
 
 /* Workspace for utterances of up to max_frames mel frames (prompt + new; two per speech token). */
 int s3cfm_create(int32_t device, int32_t max_frames, s3cfm** out);
+/* The same with room for max_batch utterances per s3cfm_solve_batch call (1 .. S3CFM_MAX_BATCH; about 19 KiB of workspace per
+ * frame and utterance). */
+int s3cfm_create_batched(int32_t device, int32_t max_frames, int32_t max_batch, s3cfm** out);
 int s3cfm_destroy(s3cfm* h);
 
 /* One tensor of `S3Token2Wav.flow.state_dict()` whose name starts with `decoder.estimator.`, fp32 host memory, PyTorch
@@ -47,6 +52,17 @@ int s3cfm_estimator(s3cfm* h, const float* x_dev, const float* mu_dev, const flo
 int s3cfm_solve(s3cfm* h, const float* mu_dev, const float* spks_dev, const float* cond_dev, const float* noise_dev, int32_t L,
                 const float* t_span, int32_t n_timesteps, double cfg_rate, float* mel_dev, void* stream);
 
+/* n_utt independent `CausalConditionalCFM.forward` calls (flow_matching.py:203-228; the reference makes them one after the
+ * other, one per utterance: flow.py:256 asserts batch 1) through shared kernel launches, so that short utterances fill the
+ * GPU together.  Utterance u has frames[u] mel frames (host memory, 1 .. L); mu_dev, cond_dev, noise_dev, mel_dev are
+ * [n_utt][80][L], spks_dev [n_utt][80]; an utterance's columns from frames[u] on must hold finite values on input (zeros) and
+ * are unspecified in mel_dev.  Every utterance's result equals its own s3cfm_solve call's up to the rounding of differently
+ * ordered fp32 sums (the launches may split their reductions differently at a different size).  s3cfm_solve is this call with
+ * n_utt = 1. */
+int s3cfm_solve_batch(s3cfm* h, int32_t n_utt, const int32_t* frames, int32_t L, const float* mu_dev, const float* spks_dev,
+                      const float* cond_dev, const float* noise_dev, const float* t_span, int32_t n_timesteps, double cfg_rate,
+                      float* mel_dev, void* stream);
+
 /* Single operations of the estimator, for tests and timing; both run the launch once, then `iters` more times between two
  * events and report the average in *avg_us (may be NULL).  Tensors hold the two guidance rows: [2][channels][ld] fp32.
  *
@@ -63,9 +79,12 @@ int s3cfm_op_linear(const float* x_dev, int32_t Cin, int32_t L, int32_t ld, cons
 
 /* Self-attention of a transformer block (the diffusers default processor as matcha/transformer.py:267-273 calls it: 8 heads x
  * 64, softmax(q k^T / 8) v, every frame attends to every frame): qk_dev [2][1024][ld] (q in channels 0..511, k in 512..1023,
- * head h at 64 h ..), vt_dev [2][ld][576] frame-major (channels 0..511 used) -> o_dev [2][512][ld]. */
-int s3cfm_op_attention(const float* qk_dev, const float* vt_dev, int32_t L, int32_t ld, float* o_dev, int32_t iters, float* avg_us,
-                       void* stream);
+ * head h at 64 h ..), vt_dev [2][ld][576] frame-major (channels 0..511 used) -> o_dev [2][512][ld].
+ * With n_utt > 1 the tensors hold 2 n_utt rows (rows 2 u and 2 u + 1 belong to utterance u) and keys [n_utt] (host memory, may
+ * be NULL = L each) gives the number of leading frames of each utterance that are real: queries see only those keys, and
+ * the outputs of queries past them are unspecified but finite, as s3cfm_solve_batch uses it. */
+int s3cfm_op_attention(const float* qk_dev, const float* vt_dev, int32_t n_utt, const int32_t* keys, int32_t L, int32_t ld, float* o_dev,
+                       int32_t iters, float* avg_us, void* stream);
 
 #ifdef __cplusplus
 }

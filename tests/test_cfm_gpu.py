@@ -206,6 +206,98 @@ def test_attention_kernel_against_fp64(L):
     assert (o.double().cpu() - want).abs().max().item() < 2e-5
 
 
+def test_attention_kernel_with_several_utterances_and_their_own_key_counts():
+    """Three utterances of 150, 97 and 33 real frames in one launch at L = 150: every query of an utterance sees only that
+    utterance's keys (fp64 softmax over the first keys[u] frames); what lies past them in q, k, v is large on purpose, so a
+    key that leaks would show.  Outputs of the padding queries only have to be finite."""
+    from chatterbox_vllm_amd.cfm_decoder import attention_op
+    L, keys = 150, [150, 97, 33]
+    g = torch.Generator().manual_seed(77)
+    q = 2.0 * torch.randn(6, 512, L, generator=g)
+    k = 2.0 * torch.randn(6, 512, L, generator=g)
+    v = torch.randn(6, 512, L, generator=g)
+    for u, n in enumerate(keys):
+        k[2 * u:2 * u + 2, :, n:] *= 5.0
+        v[2 * u:2 * u + 2, :, n:] += 100.0
+    o, _ = attention_op(q.cuda(), k.cuda(), v.cuda(), keys=keys)
+    assert torch.isfinite(o).all()
+    for u, n in enumerate(keys):
+        r = slice(2 * u, 2 * u + 2)
+        qh, kh, vh = (t[r, :, :n].double().reshape(2, 8, 64, n) for t in (q, k, v))
+        a = torch.softmax(qh.transpose(2, 3) @ kh / 8.0, dim=-1)
+        want = (vh @ a.transpose(2, 3)).reshape(2, 512, n)
+        assert (o[r, :, :n].double().cpu() - want).abs().max().item() < 2e-5
+
+
+@pytest.fixture(scope="module")
+def cfm4(sd):
+    from chatterbox_vllm_amd.cfm_decoder import CausalConditionalCFM
+    m = CausalConditionalCFM(sd, max_frames=300, generator=torch.Generator().manual_seed(3), max_batch=4)
+    yield m
+    m.shutdown()
+
+
+def test_batched_solve_gives_every_utterance_its_own_result(cfm4, sd):
+    """Four utterances of different lengths through shared launches: each result is held to the fp64 restatement of that
+    utterance alone (the bar of the single-utterance solve) and sits within fp32 rounding of the single-utterance call."""
+    from oracle import cfm_oracle as O
+    frames, prompts = [96, 131, 40, 70], [30, 50, 8, 20]
+    ins = [CW.synthetic_inputs(n, p, seed=20 + i) for i, (n, p) in enumerate(zip(frames, prompts))]
+    L = max(frames)
+    pad = lambda t: torch.nn.functional.pad(t, (0, L - t.shape[2]))
+    ts = CW.t_span(10)
+    got = cfm4.solve_euler_batch(torch.cat([pad(d["noise"]) for d in ins]), ts, torch.cat([pad(d["mu"]) for d in ins]),
+                                 torch.cat([d["spks"] for d in ins]), torch.cat([pad(d["cond"]) for d in ins]), frames)
+    assert got.shape == (4, 80, L)
+    for u, d in enumerate(ins):
+        mine = got[u:u + 1, :, :frames[u]]
+        want = O.solve_euler(sd, d["noise"], ts, d["mu"], d["spks"], d["cond"], dtype=torch.float64)
+        assert _rel(mine, want) < 1e-4
+        single = cfm4.solve_euler(d["noise"], ts, d["mu"], d["spks"], d["cond"])
+        assert _rel(mine, single.double().cpu()) < 2e-5
+    # a batch of one is the single call, bit for bit; a second batch after a longer one leaves no trace
+    one = cfm4.solve_euler_batch(ins[2]["noise"], ts, ins[2]["mu"], ins[2]["spks"], ins[2]["cond"], [frames[2]])
+    assert torch.equal(one, cfm4.solve_euler(ins[2]["noise"], ts, ins[2]["mu"], ins[2]["spks"], ins[2]["cond"]))
+    again = cfm4.solve_euler_batch(torch.cat([pad(d["noise"]) for d in ins]), ts, torch.cat([pad(d["mu"]) for d in ins]),
+                                   torch.cat([d["spks"] for d in ins]), torch.cat([pad(d["cond"]) for d in ins]), frames)
+    for u in range(4):
+        assert torch.equal(again[u, :, :frames[u]], got[u, :, :frames[u]])
+
+
+def test_batched_solve_limits(cfm4):
+    d = CW.synthetic_inputs(50, 10)
+    five = lambda t: torch.cat([t] * 5)
+    with pytest.raises(ValueError):
+        cfm4.solve_euler_batch(five(d["noise"]), CW.t_span(2), five(d["mu"]), five(d["spks"]), five(d["cond"]), [50] * 5)
+
+
+def test_chain_on_several_utterances_at_once(sd):
+    """S3Token2Wav.inference_batch: three utterances of one voice through the flow-matching stage together give the
+    waveforms of three inference calls, to the rounding the shared launches allow on the mel (2e-5 of its range) and what
+    the vocoder makes of that."""
+    from chatterbox_vllm_amd import flow_weights as FW, hift_weights as HW
+    from chatterbox_vllm_amd.s3gen import S3Token2Wav
+    flow_sd = dict(FW.synthetic_state_dict())
+    flow_sd.update(sd)
+    torch.manual_seed(11)
+    s3 = S3Token2Wav(flow_sd, HW.synthetic_state_dict(), max_tokens=64, max_batch=3)
+    g = torch.Generator().manual_seed(8)
+    ref = {"prompt_token": FW.synthetic_tokens(14, seed=3).view(1, -1),
+           "prompt_feat": 2.0 * torch.randn(1, 28, 80, generator=g) - 4.0,
+           "embedding": torch.randn(1, 192, generator=g)}
+    toks = [FW.synthetic_tokens(n, seed=40 + n) for n in (30, 12, 45)]
+    ins = [s3.encoder.decoder_inputs(t.view(1, -1), ref["prompt_token"], ref["prompt_feat"], ref["embedding"]) for t in toks]
+    mels = s3.decoder.forward_batch([d["mu"] for d in ins], [d["spks"] for d in ins], [d["cond"] for d in ins])
+    for d, t, mel in zip(ins, toks, mels):
+        one, _ = s3.decoder(mu=d["mu"], mask=d["mask"], spks=d["spks"], cond=d["cond"], n_timesteps=10)
+        assert mel.shape == one.shape == (1, 80, 28 + 2 * t.numel())
+        assert _rel(mel, one.double().cpu()) < 2e-5
+    wavs = s3.inference_batch(toks, ref, seed=3)
+    for t, wav in zip(toks, wavs):
+        assert wav.shape == (1, 2 * t.numel() * 480) and torch.isfinite(wav).all() and not wav[0, :480].any()
+    s3.shutdown()
+
+
 def test_two_chains_in_flight_give_the_bits_of_one_at_a_time(sd):
     """Several utterances in flight (bench.py's s3gen_job leg): two token -> waveform chains, each with its own handle set,
     stream and host thread, running at the same time return bit for bit what one chain returns for the same utterances one

@@ -1,5 +1,5 @@
 """The benchmark job's chunks through the token -> waveform chain with one or several utterances in flight (bench.py's
-s3gen_job leg on chunk lengths like the job's): python tools/bench_s3gen_job.py [--workers 1 2 3] [--chunks 154]"""
+s3gen_job leg on chunk lengths like the job's): python tools/bench_s3gen_job.py [--variants 1x1 3x1 1x8 2x4] [--chunks 154]"""
 import argparse
 import json
 import os
@@ -19,7 +19,8 @@ def job_lengths(n, seed=5):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workers", type=int, nargs="+", default=[1, 2, 3])
+    ap.add_argument("--variants", nargs="+", default=["1x1", "3x1", "1x8", "2x4"], help="<utterances in flight>x<utterances per call>")
     ap.add_argument("--chunks", type=int, default=154)
     args = ap.parse_args()
-    print(json.dumps(bench.s3gen_job_leg(0, job_lengths(args.chunks), workers=tuple(args.workers)), indent=1))
+    variants = tuple(tuple(int(v) for v in s.split("x")) for s in args.variants)
+    print(json.dumps(bench.s3gen_job_leg(0, job_lengths(args.chunks), variants=variants), indent=1))

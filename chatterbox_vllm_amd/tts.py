@@ -167,7 +167,8 @@ class ChatterboxTTS:
             from .s3gen import S3Token2Wav
             s3_sd = load_file(str(ckpt_dir / "s3gen.safetensors"))
             kwargs["s3gen"] = S3Token2Wav({k[len("flow."):]: v for k, v in s3_sd.items() if k.startswith("flow.")},
-                                          {k[len("mel2wav."):]: v for k, v in s3_sd.items() if k.startswith("mel2wav.")})
+                                          {k[len("mel2wav."):]: v for k, v in s3_sd.items() if k.startswith("mel2wav.")},
+                                          max_batch=min(8, max(1, max_batch_size)))
         cfg = cls.variant_config(variant)
         # the backbone's depth is the checkpoint's (30 for the published ones): a cut-down checkpoint loads as what it is
         depth = 1 + max((int(k.split(".")[2]) for k in sd if k.startswith("tfmr.layers.")), default=-1)
@@ -205,7 +206,8 @@ class ChatterboxTTS:
             from .s3gen import S3Token2Wav
             flow_sd = dict(flow_weights.synthetic_state_dict())
             flow_sd.update(cfm_weights.synthetic_state_dict())
-            kwargs["s3gen"] = S3Token2Wav(flow_sd, hift_weights.synthetic_state_dict(), max_tokens=kwargs.get("max_model_len", 1000) + 256)
+            kwargs["s3gen"] = S3Token2Wav(flow_sd, hift_weights.synthetic_state_dict(), max_tokens=kwargs.get("max_model_len", 1000) + 256,
+                                          max_batch=min(8, max(1, kwargs.get("max_batch_size", 10))))
         cfg = cls.variant_config(variant)
         if n_layers is not None:
             cfg = T3ModelConfig(n_layers=n_layers, text_vocab=cfg.text_vocab)
@@ -309,16 +311,26 @@ class ChatterboxTTS:
         self.last_t3_seconds = time.time() - t0
         self.last_request_outputs = outs
         print(f"[T3] Speech Token Generation time: {self.last_t3_seconds:.2f}s")
-        results = []
-        for it, ro in zip(items, outs):
-            for out in ro.outputs:
-                toks = postprocess_speech_ids(out.token_ids, it["prompt"])
-                if self.s3gen is not None:
-                    wav, _ = self.s3gen.inference(speech_tokens=toks.to(self.target_device), ref_dict=s3gen_ref,
+        all_toks = [postprocess_speech_ids(out.token_ids, it["prompt"]) for it, ro in zip(items, outs) for out in ro.outputs]
+        if self.s3gen is None:
+            return all_toks
+        results: List[Any] = [None] * len(all_toks)
+        per_call = getattr(self.s3gen, "max_batch", 1)
+        if per_call > 1 and hasattr(self.s3gen, "inference_batch"):
+            # the reference takes the utterances through S3Gen one after the other (tts.py:489-493); here those of similar
+            # length share the flow-matching stage's launches
+            order = sorted((i for i, t in enumerate(all_toks) if t.numel() > 0), key=lambda i: -all_toks[i].numel())
+            for j in range(0, len(order), per_call):
+                group = order[j:j + per_call]
+                wavs = self.s3gen.inference_batch([all_toks[i].to(self.target_device) for i in group], s3gen_ref,
                                                   n_timesteps=diffusion_steps)
-                    results.append(postprocess_waveform(wav, int(toks.numel()), self.sr).cpu())
-                else:
-                    results.append(toks)
+                for i, wav in zip(group, wavs):
+                    results[i] = postprocess_waveform(wav, int(all_toks[i].numel()), self.sr).cpu()
+        for i, toks in enumerate(all_toks):
+            if results[i] is None:
+                wav, _ = self.s3gen.inference(speech_tokens=toks.to(self.target_device), ref_dict=s3gen_ref,
+                                              n_timesteps=diffusion_steps)
+                results[i] = postprocess_waveform(wav, int(toks.numel()), self.sr).cpu()
         return results
 
     def shutdown(self):

@@ -135,7 +135,7 @@ def test_from_local_on_a_checkpoint_directory(tmp_path, golden_dir, monkeypatch)
 def test_text_to_waveform_with_the_token_to_waveform_chain_attached(text_fx, monkeypatch):
     """``generate`` with the S3Gen stages attached returns waveforms, as the reference's does (tts.py:489-493): per prompt
     the waveform is the chain's for exactly the speech tokens the token-only facade returns, 2 mel frames and 960 samples
-    per token, 24 kHz."""
+    per token, 24 kHz.  The chain takes the prompts of a call through the flow-matching stage together."""
     monkeypatch.setenv("CHATTERBOX_DETERMINISTIC", "1")
     monkeypatch.setenv("CHATTERBOX_CFG_SCALE", "0.5")
     torch.manual_seed(5)                                           # the flow-matching decoder draws its fixed noise once
@@ -148,12 +148,15 @@ def test_text_to_waveform_with_the_token_to_waveform_chain_attached(text_fx, mon
     toks = tts.generate(EXAMPLE_PROMPTS[:2], max_tokens=40)
     assert len(wavs) == 2 and all(t.numel() > 0 for t in toks)
     from chatterbox_vllm_amd.tts import postprocess_waveform
-    for wav, t in zip(wavs, toks):
-        again, _ = s3.inference(speech_tokens=t.cuda(), ref_dict=ref, n_timesteps=4)
-        assert again.shape == (1, 960 * t.numel())
+    # the facade hands the utterances to the chain longest first, max_batch at a time (here both in one call)
+    assert s3.max_batch == 3
+    order = sorted(range(2), key=lambda i: -toks[i].numel())
+    again = dict(zip(order, s3.inference_batch([toks[i].cuda() for i in order], ref, n_timesteps=4)))
+    for i, (wav, t) in enumerate(zip(wavs, toks)):
+        assert again[i].shape == (1, 960 * t.numel())
         # the facade returns the chain's waveform after the reference's alignment cap and RMS tail trim (tts.py:495-541)
         assert wav.dtype == torch.float32 and torch.isfinite(wav).all() and 0 < wav.shape[1] <= 960 * t.numel()
-        assert torch.equal(postprocess_waveform(again, t.numel()).cpu(), wav)
+        assert torch.equal(postprocess_waveform(again[i], t.numel()).cpu(), wav)
         assert not wav[0, :480].any() and wav.abs().max() > 0
     tts.s3gen = s3
     tts.shutdown()

@@ -287,16 +287,17 @@ def vocoder_leg(device, batch=8, frames=500, iters=5):
     return rec
 
 
-def flow_decoder_leg(device, frames=1000, n_timesteps=10, iters=3):
+def flow_decoder_leg(device, frames=1000, n_timesteps=10, iters=3, per_call=8):
     """The token -> waveform side's middle stage: the flow-matching decoder (mu -> mel, fp32), one utterance of `frames`
     mel frames (20 s at 1000, prompt included), `n_timesteps` Euler steps of two estimator rows each, inputs resident in
     HBM.  Its roofline is the fp32 matrix pipe: algorithmic FLOP of the estimator's matrix products
     (cfm_weights.estimator_flop) over the HIP-event time of the whole solve, so layer norms and launch gaps count against
-    it.  The CPU figure is the restatement (torch fp32) on the same utterance, once."""
+    it.  `per_call` utterances of the same length through shared launches (s3cfm_solve_batch) are timed beside it.  The CPU
+    figure is the restatement (torch fp32) on the same utterance, once."""
     from chatterbox_vllm_amd import cfm_weights as CW
     from chatterbox_vllm_amd.cfm_decoder import CausalConditionalCFM
     sd = CW.synthetic_state_dict()
-    m = CausalConditionalCFM(sd, max_frames=frames, device=device)
+    m = CausalConditionalCFM(sd, max_frames=frames, device=device, max_batch=per_call)
     dev = f"cuda:{device}"
     inp = {k: v.to(dev) for k, v in CW.synthetic_inputs(frames, frames // 3).items()}
     ts = CW.t_span(n_timesteps)
@@ -311,6 +312,13 @@ def flow_decoder_leg(device, frames=1000, n_timesteps=10, iters=3):
     torch.cuda.synchronize(device)
     wall = (time.perf_counter() - t0) / iters
     ev_ms = e0.elapsed_time(e1) / iters
+    rep8 = {k: torch.cat([v] * per_call) for k, v in inp.items()}
+    m.solve_euler_batch(rep8["noise"], ts, rep8["mu"], rep8["spks"], rep8["cond"], [frames] * per_call)
+    e0.record()
+    m.solve_euler_batch(rep8["noise"], ts, rep8["mu"], rep8["spks"], rep8["cond"], [frames] * per_call)
+    e1.record()
+    torch.cuda.synchronize(device)
+    ev8_ms = e0.elapsed_time(e1)
     m.shutdown()
     flop = CW.estimator_flop(frames) * n_timesteps
     achieved = flop / (ev_ms * 1e-3) / 1e12
@@ -321,6 +329,9 @@ def flow_decoder_leg(device, frames=1000, n_timesteps=10, iters=3):
            "roofline": {"bound": "mfma", "kernel": "lin_kernel + attn_kernel (about 3 700 launches of a solve)", "achieved": round(achieved, 2),
                         "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
                         "traffic": None, "event_ms_per_call": round(ev_ms, 3), "algorithmic_gflop_per_call": round(flop / 1e9, 1)}}
+    rec["several_per_call"] = {"utterances_per_call": per_call, "value": round(per_call * frames * 0.02 / (ev8_ms * 1e-3), 1),
+                               "event_ms_per_call": round(ev8_ms, 3), "achieved": round(per_call * flop / (ev8_ms * 1e-3) / 1e12, 2),
+                               "frac": round(per_call * flop / (ev8_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)}
     from oracle import cfm_oracle as CO
     small = frames
     inp_c = CW.synthetic_inputs(small, small // 3)

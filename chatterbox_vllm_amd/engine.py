@@ -37,6 +37,12 @@ class SamplingParams:
     max_tokens: int = 16
     stop_token_ids: Optional[Sequence[int]] = None
     seed: Optional[int] = None
+    # Accepted for callers that pass them (the reference's server does for the multilingual model,
+    # openai_tts_server.py:415-421) and without effect here: they steer vLLM's detokenizer and its tokenizer-level
+    # end-of-sequence id, neither of which the speech-token path has (it stops on stop_token_ids).
+    ignore_eos: bool = False
+    skip_special_tokens: bool = True
+    spaces_between_special_tokens: bool = True
 
     def __post_init__(self):
         if self.temperature < 0:

@@ -9,16 +9,14 @@ language restriction to the checkpoint variant (:117-119, :351-363).
 """
 from __future__ import annotations
 
-import time
 from pathlib import Path
 from typing import Any, Dict, List, Optional, Union
 
 import torch
 
 from .config import T3ModelConfig
-from .engine import SamplingParams
-from .text_utils import SUPPORTED_LANGUAGES, punc_norm, batch_max_tokens, _env_flag
-from .tts import ChatterboxTTS, REPO_ID, STOP_OFFSET_ID, postprocess_speech_ids
+from .text_utils import SUPPORTED_LANGUAGES, punc_norm
+from .tts import ChatterboxTTS, REPO_ID
 
 
 class ChatterboxMultilingualTTS(ChatterboxTTS):
@@ -82,27 +80,7 @@ class ChatterboxMultilingualTTS(ChatterboxTTS):
             if lang:
                 it["tokenization_kwargs"] = {"language_id": lang.lower()}
             items.append(it)
-        temp_use, top_p_use = temperature, top_p
-        if any(langs):
-            temp_use, top_p_use = min(temperature, 0.5), min(top_p, 0.5)
-        if _env_flag("CHATTERBOX_DETERMINISTIC"):
-            temp_use, top_p_use = 0.0, 1.0
-        cap = batch_max_tokens([it["prompt"] for it in items], max_tokens, self.max_model_len)
-        sp = SamplingParams(temperature=temp_use, stop_token_ids=[STOP_OFFSET_ID], max_tokens=cap, top_p=top_p_use,
-                            repetition_penalty=repetition_penalty, *args, **kwargs)
-        t0 = time.time()
-        outs = self.t3.generate(items, sampling_params=sp)
-        self.last_t3_seconds = time.time() - t0
-        self.last_request_outputs = outs
-        print(f"[T3] Speech Token Generation time: {self.last_t3_seconds:.2f}s")
-        results = []
-        for it, ro in zip(items, outs):
-            for out in ro.outputs:
-                toks = postprocess_speech_ids(out.token_ids, it["prompt"])
-                if self.s3gen is not None:
-                    wav, _ = self.s3gen.inference(speech_tokens=toks.to(self.target_device), ref_dict=s3gen_ref,
-                                                  n_timesteps=diffusion_steps)
-                    results.append(wav.cpu())
-                else:
-                    results.append(toks)
-        return results
+        # the sampling clamp applies when any language id is given (mtl_tts.py:453-459); the waveforms get the alignment cap
+        # and tail trim (mtl_tts.py:592-644) in render_waveforms
+        toks = self._speech_tokens(items, any(langs), temperature, top_p, max_tokens, repetition_penalty, *args, **kwargs)
+        return toks if self.s3gen is None else self.render_waveforms(toks, s3gen_ref, diffusion_steps)

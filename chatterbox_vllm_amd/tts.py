@@ -296,24 +296,41 @@ class ChatterboxTTS:
                              + ", ".join(self.get_supported_languages().keys()))
         cond_emb = self.update_exaggeration(cond_emb, exaggeration)
         items = self._request_items(prompts, language_id, cond_emb)
+        toks = self._speech_tokens(items, bool(language_id), temperature, top_p, max_tokens, repetition_penalty,
+                                   *args, **kwargs)
+        return toks if self.s3gen is None else self.render_waveforms(toks, s3gen_ref, diffusion_steps)
+
+    def _speech_tokens(self, items: List[dict], clamp: bool, temperature: float, top_p: float, max_tokens: int,
+                       repetition_penalty: float, *args, per_prompt_max_tokens: bool = False, **kwargs) -> List[torch.Tensor]:
+        """Request items -> one tensor of speech tokens each (the T3 half of the reference's ``generate_with_conds``).
+
+        ``per_prompt_max_tokens`` has no counterpart in the reference, whose calls share one ``max_tokens`` (the smallest
+        prompt's, tts.py:378-393): with it every prompt gets the cap it would get in a call of its own, which is what lets
+        the streaming server take the chunks of a request through one batched call and still return what chunk-by-chunk
+        calls return."""
         temp_use, top_p_use = temperature, top_p
-        if language_id:                                                # tts.py:350-356
+        if clamp:                                                      # tts.py:350-356
             temp_use, top_p_use = min(temperature, 0.5), min(top_p, 0.5)
         if _env_flag("CHATTERBOX_DETERMINISTIC"):                      # tts.py:358-362
             temp_use, top_p_use = 0.0, 1.0
-        cap = batch_max_tokens([it["prompt"] for it in items], max_tokens, self.max_model_len)
+        prompts = [it["prompt"] for it in items]
         # NOTE the reference forwards min_p only when the caller passes it through **kwargs (tts.py:410-417):
         # the named `min_p` parameter is accepted and not used.
-        sp = SamplingParams(temperature=temp_use, stop_token_ids=[STOP_OFFSET_ID], max_tokens=cap, top_p=top_p_use,
-                            repetition_penalty=repetition_penalty, *args, **kwargs)
+        def params(group):
+            return SamplingParams(temperature=temp_use, stop_token_ids=[STOP_OFFSET_ID],
+                                  max_tokens=batch_max_tokens(group, max_tokens, self.max_model_len), top_p=top_p_use,
+                                  repetition_penalty=repetition_penalty, *args, **kwargs)
+        sps = [params([p]) for p in prompts] if per_prompt_max_tokens else params(prompts)
         t0 = time.time()
-        outs = self.t3.generate(items, sampling_params=sp)
+        outs = self.t3.generate(items, sampling_params=sps)
         self.last_t3_seconds = time.time() - t0
         self.last_request_outputs = outs
         print(f"[T3] Speech Token Generation time: {self.last_t3_seconds:.2f}s")
-        all_toks = [postprocess_speech_ids(out.token_ids, it["prompt"]) for it, ro in zip(items, outs) for out in ro.outputs]
-        if self.s3gen is None:
-            return all_toks
+        return [postprocess_speech_ids(out.token_ids, it["prompt"]) for it, ro in zip(items, outs) for out in ro.outputs]
+
+    def render_waveforms(self, all_toks: List[torch.Tensor], s3gen_ref: Dict[str, Any], diffusion_steps: int = 10) -> List[torch.Tensor]:
+        """Speech tokens -> waveforms [1, N] on the CPU through the attached token -> waveform object, each with the
+        reference's alignment cap and RMS tail trim (tts.py:489-541)."""
         results: List[Any] = [None] * len(all_toks)
         per_call = getattr(self.s3gen, "max_batch", 1)
         if per_call > 1 and hasattr(self.s3gen, "inference_batch"):

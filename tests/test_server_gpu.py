@@ -9,6 +9,7 @@ import pytest
 import torch
 
 from chatterbox_vllm_amd import server as S
+from chatterbox_vllm_amd.text_utils import punc_norm
 from chatterbox_vllm_amd.tts import ChatterboxTTS
 
 pytestmark = pytest.mark.gpu
@@ -40,7 +41,7 @@ def test_streamed_request_equals_chunk_by_chunk_generate_calls(monkeypatch):
         assert r.status_code == 200 and r.headers["content-type"] == "audio/pcm;rate=24000;channels=1"
         # the batched token call gave every chunk its own cap and ran them together
         ros = tts.last_request_outputs
-        assert [ro.prompt for ro in ros] == ["[START]" + c + "[STOP]" for c in chunks[1:]]
+        assert [ro.prompt for ro in ros] == ["[START]" + punc_norm(c) + "[STOP]" for c in chunks[1:]]
         lens = [len(ro.outputs[0].token_ids) for ro in ros]
         assert len(set(lens)) > 1 and all(ro.outputs[0].finish_reason == "length" for ro in ros)
         want = bytes(2 * 240)

@@ -111,6 +111,8 @@ def run_job(eng, job, conds, stats=None):
             if s.decode_requests:
                 stats["decode_steps"] += 1
                 stats["decode_rows"] += s.decode_rows
+                if "decode_requests" in stats:
+                    stats["decode_requests"] += s.decode_requests
                 stats["decode_ctx_tokens"] += s.decode_ctx_tokens
     return n, [ids[r] for r in rids]
 
@@ -159,12 +161,19 @@ def _pmc_traffic(kernel_class):
     return rec.get(kernel_class)
 
 
+def stats_tokens(eng):
+    """Tokens the decode steps of the event-timed pass sampled (requests per step summed), or 0 when not recorded."""
+    return getattr(eng, "_timed_decode_tokens", 0)
+
+
 def roofline_of(eng, job, conds, use_pmc):
     """One more pass of the job with every launch bracketed by HIP events bound to its dispatch; the roofline object of
     the dominant HBM-streaming kernel plus the per-class breakdown."""
     eng.set_kernel_timing(True)
     t1 = time.perf_counter()
-    run_job(eng, job, conds)
+    st = {"decode_steps": 0, "decode_rows": 0, "decode_ctx_tokens": 0, "decode_requests": 0}
+    run_job(eng, job, conds, st)
+    eng._timed_decode_tokens = st.get("decode_requests", 0)
     timed_pass = time.perf_counter() - t1
     kd, kp = eng.kernel_times("decode"), eng.kernel_times("prefill")
     eng.set_kernel_timing(False)
@@ -192,6 +201,19 @@ def roofline_of(eng, job, conds, use_pmc):
                  "GBps": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1)} for k, v in d.items()}
         for ph, d in (("decode", kd), ("prefill", kp))}
     breakdown["event_timed_pass_s"] = round(timed_pass, 3)
+    # the decode step as a whole against the HBM roofline: algorithmic bytes of all its launches (weights once per step,
+    # K/V of every stream, row gathers) over the summed launch durations; tokens = sampler rows of the decode steps
+    d_ms = sum(v["ms"] for v in kd.values())
+    d_steps = max(1, kd.get("sample", {}).get("launches", 0))
+    d_bytes = sum(v["bytes"] for v in kd.values())
+    d_tokens = stats_tokens(eng)
+    breakdown["decode_step"] = {
+        "steps": d_steps, "launch_ms_per_step": round(d_ms / d_steps, 4),
+        "algorithmic_MB_per_step": round(d_bytes / d_steps / 1e6, 1),
+        "achieved_GBps": round(d_bytes / max(d_ms, 1e-9) / 1e6, 1),
+        "frac_of_hbm_peak": round(d_bytes / max(d_ms, 1e-9) / 1e6 / HBM_PEAK_GBS, 4),
+        "decode_only_tokens_per_s": round(d_tokens / max(d_ms, 1e-9) * 1e3, 1) if d_tokens else None,
+    }
     return roof, breakdown
 
 

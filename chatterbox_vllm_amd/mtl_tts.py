@@ -82,5 +82,6 @@ class ChatterboxMultilingualTTS(ChatterboxTTS):
             items.append(it)
         # the sampling clamp applies when any language id is given (mtl_tts.py:453-459); the waveforms get the alignment cap
         # and tail trim (mtl_tts.py:592-644) in render_waveforms
+        tokens_only = kwargs.pop("tokens_only", False)
         toks = self._speech_tokens(items, any(langs), temperature, top_p, max_tokens, repetition_penalty, *args, **kwargs)
-        return toks if self.s3gen is None else self.render_waveforms(toks, s3gen_ref, diffusion_steps)
+        return toks if self.s3gen is None or tokens_only else self.render_waveforms(toks, s3gen_ref, diffusion_steps)

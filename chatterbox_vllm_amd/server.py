@@ -251,23 +251,21 @@ class SpeechService:
             return
         with self._lock:
             ref, cond = tts.get_audio_conditionals(audio_prompt_path)
-            saved, tts.s3gen = tts.s3gen, None                       # tokens only from this call; rendering follows per chunk
-            try:
-                toks = tts.generate_with_conds(prompts=rest, s3gen_ref=ref, cond_emb=cond, language_id=lang,
-                                               temperature=temperature, exaggeration=exaggeration,
-                                               max_tokens=tts.max_model_len, **self._facade_defaults(),
-                                               per_prompt_max_tokens=True)
-            finally:
-                tts.s3gen = saved
+            toks = tts.generate_with_conds(prompts=rest, s3gen_ref=ref, cond_emb=cond, language_id=lang,
+                                           temperature=temperature, exaggeration=exaggeration,
+                                           max_tokens=tts.max_model_len, **self._facade_defaults(),
+                                           per_prompt_max_tokens=True, tokens_only=True)   # rendering follows per chunk
         for tok in toks:
             with self._lock:
                 wav = tts.render_waveforms([tok], ref, diffusion_steps)[0]
             yield tail_ramp(wav, self.sr)
 
     def _facade_defaults(self) -> Dict[str, Any]:
-        """``generate``'s own defaults where they differ from ``generate_with_conds``'s (tts.py:259-288: top_p 0.8 against
-        1.0), so that a chunk taken through the batched call is sampled as ``generate`` would sample it."""
-        return {} if self._multilingual() else {"top_p": 0.8}
+        """``generate``'s own default for ``top_p`` (tts.py:259-288: 0.8 where ``generate_with_conds`` has 1.0), so that a
+        chunk taken through the batched call is sampled as ``generate`` would sample it."""
+        import inspect
+        top_p = inspect.signature(type(self.tts).generate).parameters.get("top_p")
+        return {} if top_p is None or top_p.default is inspect.Parameter.empty else {"top_p": top_p.default}
 
     def stream_pcm_frames(self, text: str, *, frame_ms: int = 20, primer_silence_ms: int = 0, **synthesis) -> Iterator[bytes]:
         """PCM16 frames of a streamed request (openai_tts_server.py:438-528): optional leading silence so that headers and a

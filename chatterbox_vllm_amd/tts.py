@@ -296,9 +296,10 @@ class ChatterboxTTS:
                              + ", ".join(self.get_supported_languages().keys()))
         cond_emb = self.update_exaggeration(cond_emb, exaggeration)
         items = self._request_items(prompts, language_id, cond_emb)
+        tokens_only = kwargs.pop("tokens_only", False)             # package extension: stop after the T3 half (see _speech_tokens)
         toks = self._speech_tokens(items, bool(language_id), temperature, top_p, max_tokens, repetition_penalty,
                                    *args, **kwargs)
-        return toks if self.s3gen is None else self.render_waveforms(toks, s3gen_ref, diffusion_steps)
+        return toks if self.s3gen is None or tokens_only else self.render_waveforms(toks, s3gen_ref, diffusion_steps)
 
     def _speech_tokens(self, items: List[dict], clamp: bool, temperature: float, top_p: float, max_tokens: int,
                        repetition_penalty: float, *args, per_prompt_max_tokens: bool = False, **kwargs) -> List[torch.Tensor]:

@@ -97,7 +97,7 @@ class _StandInEngine:
         return torch.full((1, 240 * len(text)), 0.001 * steps + 0.01 * (len(text) % 7))
 
     def generate(self, prompts, audio_prompt_path=None, language_id="en", temperature=0.8, exaggeration=0.5,
-                 diffusion_steps=10, max_tokens=1000, **kw):
+                 diffusion_steps=10, max_tokens=1000, top_p=0.8, **kw):
         if language_id == "xx":
             raise ValueError("Unsupported language_id 'xx'")
         if prompts == "boom":
@@ -106,8 +106,8 @@ class _StandInEngine:
         return [self._wave(prompts, diffusion_steps)]
 
     def generate_with_conds(self, prompts, s3gen_ref, cond_emb, language_id="en", temperature=0.8, exaggeration=0.5,
-                            max_tokens=1000, top_p=1.0, per_prompt_max_tokens=False, **kw):
-        assert self.s3gen is None and per_prompt_max_tokens and top_p == 0.8
+                            max_tokens=1000, top_p=1.0, per_prompt_max_tokens=False, tokens_only=False, **kw):
+        assert tokens_only and per_prompt_max_tokens and top_p == 0.8
         self.calls.append(("tokens", list(prompts), max_tokens, language_id))
         return [torch.tensor([ord(ch) for ch in p]) for p in prompts]
 
@@ -135,7 +135,6 @@ def test_service_streams_first_chunk_alone_then_one_batched_token_call():
     assert eng.calls[1] == ("tokens", chunks[1:], 1000, "en")
     assert eng.calls[2:] == [("render", [len(c)], 7) for c in chunks[1:]]
     assert [w.shape[1] for w in rest] == [240 * len(c) for c in chunks[1:]]
-    assert eng.s3gen is not None                                       # put back after the token-only call
     frames = list(svc.stream_pcm_frames(TEXT, frame_ms=20, primer_silence_ms=50, diffusion_steps=7,
                                         first_chunk_diff_steps=3, first_chunk_chars=30, chunk_chars=60))
     assert frames[0] == bytes(2 * 1200)

@@ -172,3 +172,25 @@ def test_http_endpoint_over_a_stand_in_engine(fx):
         assert client.post("/v1/audio/speech", json={"input": "x", "format": "mp3"}).status_code == 422
         assert client.post("/v1/audio/speech", json={"input": "x", "frame_ms": 5}).status_code == 422
     assert not eng.shut                                               # a service handed in is left running
+
+
+def test_language_fallback_applies_to_the_multilingual_engine_only():
+    """openai_tts_server.py:406-411: a multilingual engine with no language in the request gets the script-based guess;
+    a named language is never overridden, and the English engine is never second-guessed."""
+    eng = _StandInEngine()
+    svc = S.SpeechService(eng)
+    svc.synthesize("Привет, мир!", language_id=None)
+    assert eng.calls[-1][4] is None
+    eng.variant = "multilingual"
+    svc.synthesize("Привет, мир!", language_id=None)
+    assert eng.calls[-1][4] == "ru"
+    svc.synthesize("Привет, мир!", language_id="  ")
+    assert eng.calls[-1][4] == "ru"
+    svc.synthesize("Привет, мир!", language_id="fr")
+    assert eng.calls[-1][4] == "fr"
+    svc.synthesize("plain ascii", language_id=None)
+    assert eng.calls[-1][4] is None
+    # the streamed form detects once, on the whole text, and uses it for every chunk
+    list(svc.stream_waveforms("你好，世界。今天天气很好！我们去公园散步吧。", language_id="", first_chunk_chars=10, chunk_chars=40))
+    langs = {c[-1] for c in eng.calls if c[0] in ("generate", "tokens")} - {None, "ru", "fr"}
+    assert langs == {"zh"}

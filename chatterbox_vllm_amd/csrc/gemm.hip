@@ -48,7 +48,15 @@ __device__ __forceinline__ bf16x8 dequant8(unsigned lo, unsigned hi) {
 // AM: the activation rows are attention outputs that this kernel merges itself from the per-wave softmax states of the
 // few-row split attention (EPI_SLAB, K = 1024, one row tile, KT = 2: the wave's two k-tiles are one head).
 template <int NB, int MT, int KW, int KT, int EPI, bool W8, int FN = -1, bool AM = false>
-__global__ __launch_bounds__(KW * 64) void gemm_stream_kernel(GemmArgs a) {
+__global__ __launch_bounds__(KW * 64) void gemm_stream_kernel(
+        // The leading plain arguments reach the waves in SGPRs set up at wave launch (the library is built with kernel-argument
+        // preloading; a struct argument does not qualify, its fields are fetched by scalar loads the first addresses would wait
+        // for): the fields of GemmArgs that those addresses are made of, passed a second time ahead of the struct.
+        const bf16_t* lead_A, const bf16_t* lead_Wt, const int32_t* lead_pos, const int32_t* lead_row_stream, int lead_M, int lead_N,
+        int lead_K, int lead_lda, int lead_H, int lead_flags, GemmArgs a_) {
+    GemmArgs a = a_;
+    a.A = lead_A; a.Wt = lead_Wt; a.pos = lead_pos; a.row_stream = lead_row_stream; a.M = lead_M; a.N = lead_N; a.K = lead_K;
+    a.lda = lead_lda; a.kv.H = lead_H; a.a_tiled = (lead_flags & 1) != 0; a.c_tiled = (lead_flags & 2) != 0;
     extern __shared__ __attribute__((aligned(16))) float red_raw[];
     f32x4* red = reinterpret_cast<f32x4*>(red_raw);
     __shared__ __attribute__((aligned(16))) bf16_t fn_tile[FN >= 0 ? 16 * 1024 : 8];   // one row tile, all of K
@@ -416,7 +424,8 @@ static int launch_w(const GemmArgs& a, int nblocks, hipStream_t st, int ksplit) 
         attr_set[dev] = true;
     }
     const int groups = (a.M + MT * 16 - 1) / (MT * 16);
-    T3_LAUNCH((gemm_stream_kernel<NB, MT, KW, KT, EPI, W8, FN, AM>), dim3(nblocks, groups, ksplit), dim3(KW * 64), lds, st, a);
+    T3_LAUNCH((gemm_stream_kernel<NB, MT, KW, KT, EPI, W8, FN, AM>), dim3(nblocks, groups, ksplit), dim3(KW * 64), lds, st,
+              a.A, a.Wt, a.pos, a.row_stream, a.M, a.N, a.K, a.lda, a.kv.H, (a.a_tiled ? 1 : 0) | (a.c_tiled ? 2 : 0), a);
     T3_HIP_CHECK(hipGetLastError());
     return 0;
 }

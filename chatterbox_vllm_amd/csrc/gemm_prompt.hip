@@ -54,7 +54,12 @@ template <int V> using IC = std::integral_constant<int, V>;
 }  // namespace
 
 template <int EPI, bool W8>
-__global__ __launch_bounds__(256) void gemm_prompt_kernel(GemmArgs a, int m_tiles, int n_tiles, int ksplit, int per_xcd) {
+__global__ __launch_bounds__(256) void gemm_prompt_kernel(
+        // leading plain arguments travel in preloaded SGPRs (see gemm.hip): the tile map and the fields the first addresses need
+        int m_tiles, int n_tiles, int ksplit, int per_xcd, const bf16_t* lead_A, const bf16_t* lead_Wt, int lead_M, int lead_N,
+        int lead_K, int lead_lda, int lead_H, GemmArgs a_) {
+    GemmArgs a = a_;
+    a.A = lead_A; a.Wt = lead_Wt; a.M = lead_M; a.N = lead_N; a.K = lead_K; a.lda = lead_lda; a.kv.H = lead_H;
     extern __shared__ __attribute__((aligned(16))) bf16_t plds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -288,7 +293,8 @@ static int launch_prompt_w(const GemmArgs& a, int n_tiles, int ksplit, hipStream
     const int m_tiles = (a.M + PBM - 1) / PBM;
     const int total = m_tiles * n_tiles * ksplit;
     const int per_xcd = (total + 7) / 8;
-    T3_LAUNCH((gemm_prompt_kernel<EPI, W8>), dim3(per_xcd * 8), dim3(256), lds, st, a, m_tiles, n_tiles, ksplit, per_xcd);
+    T3_LAUNCH((gemm_prompt_kernel<EPI, W8>), dim3(per_xcd * 8), dim3(256), lds, st, m_tiles, n_tiles, ksplit, per_xcd, a.A, a.Wt,
+              a.M, a.N, a.K, a.lda, a.kv.H, a);
     T3_HIP_CHECK(hipGetLastError());
     return 0;
 }

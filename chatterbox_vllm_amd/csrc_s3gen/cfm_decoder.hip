@@ -151,7 +151,12 @@ struct AttnArgs {
 // wave has more independent accumulators in flight (QT = 2 runs a tile 25 % faster than QT = 1); the launcher picks the QT
 // whose workgroup count packs best into the CUs (launch_attn).
 template <int QT>
-__global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256) void attn_kernel(
+        // leading plain arguments travel in preloaded SGPRs (see lin_kernel)
+        const float* lead_q, const float* lead_k, const float* lead_vt, size_t lead_qk_bs, size_t lead_vt_bs, int lead_ld, int lead_L,
+        int lead_rows, AttnArgs a_) {
+    AttnArgs a = a_;
+    a.q = lead_q; a.k = lead_k; a.vt = lead_vt; a.qk_bs = lead_qk_bs; a.vt_bs = lead_vt_bs; a.ld = lead_ld; a.L = lead_L; a.rows = lead_rows;
     __shared__ float so[4 * 32 * 64];
     __shared__ float sm[4][64], sl[4][64];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), half = lane >> 5, col = lane & 31;
@@ -160,7 +165,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
     const int npairs = a.rows * kHeads, p = blockIdx.x % npairs, qt = blockIdx.x / npairs;
     const int pair = (p & 7) * a.rows + (p >> 3);
     const int b = pair >> 3, h = pair & 7;
-    const int Lk = a.Lk[b >> 1];
+    const int Lk = a_.Lk[b >> 1];                           // indexed in the argument block itself (a scalar load), not in the copy
     if (qt * QT * 32 >= Lk) {
         // queries that are all padding: zeros keep what follows finite without the work
         for (int i = tid; i < 64 * QT * 32; i += 256) {
@@ -301,7 +306,14 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
 // partial sums meet in LDS in wave order (8 waves when the launch has under two workgroups per CU; 2 parts x 2 frame tiles
 // when it has plenty); KSPLIT = 1: four waves take four neighbouring 32-frame tiles instead.
 template <int KSPLIT, int MB, int OUT_ACT, bool LN_IN>
-__global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void lin_kernel(LinArgs a) {
+__global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void lin_kernel(
+        // Leading plain arguments reach the waves in SGPRs set up at wave launch (the library is built with kernel-argument
+        // preloading, which takes no struct): the fields of LinArgs that the first addresses are made of, passed a second time.
+        const float* lead_x, const float* lead_wt, size_t lead_x_bs, int lead_x_ld, int lead_Cin, int lead_CoutPad, int lead_K,
+        int lead_L, int lead_pad, int lead_Cout, LinArgs a_) {
+    LinArgs a = a_;
+    a.x = lead_x; a.wt = lead_wt; a.x_bs = lead_x_bs; a.x_ld = lead_x_ld; a.Cin = lead_Cin; a.CoutPad = lead_CoutPad; a.K = lead_K;
+    a.L = lead_L; a.pad = lead_pad; a.Cout = lead_Cout;
     constexpr int PF = 4;
     constexpr int RW = 16 * MB;                                // accumulator rows per lane: MB blocks of 32 channels per wave
     static_assert(MB == 2 || (MB == 1 && KSPLIT <= 4), "one block per wave needs at least four rows per wave to finish");
@@ -630,14 +642,15 @@ int launch_lin(const LinArgs& a, int out_act, int rows, hipStream_t st) {
     }
     const int ntw = ks == 8 ? 1 : 4 / ks;
     const dim3 grid((L + 32 * ntw - 1) / (32 * ntw), blocks == 2 ? mb : a.CoutPad / 32, rows), block(ks == 8 ? 512 : 256);
+#define LIN_LEAD(a) (a).x, (a).wt, (a).x_bs, (a).x_ld, (a).Cin, (a).CoutPad, (a).K, (a).L, (a).pad, (a).Cout
 #define S3_LIN_LAUNCH(KS, MB)                                                                                             \
     do {                                                                                                                  \
-        if (a.rsum && out_act == OUT_GELU) hipLaunchKernelGGL((lin_kernel<KS, MB, OUT_GELU, true>), grid, block, 0, st, a);   \
-        else if (a.rsum) hipLaunchKernelGGL((lin_kernel<KS, MB, OUT_NONE, true>), grid, block, 0, st, a);                     \
-        else if (out_act == OUT_GELU) hipLaunchKernelGGL((lin_kernel<KS, MB, OUT_GELU, false>), grid, block, 0, st, a);       \
-        else if (out_act == OUT_SWISH) hipLaunchKernelGGL((lin_kernel<KS, MB, OUT_SWISH, false>), grid, block, 0, st, a);     \
-        else if (out_act == OUT_LRELU) hipLaunchKernelGGL((lin_kernel<KS, MB, OUT_LRELU, false>), grid, block, 0, st, a);     \
-        else hipLaunchKernelGGL((lin_kernel<KS, MB, OUT_NONE, false>), grid, block, 0, st, a);                                \
+        if (a.rsum && out_act == OUT_GELU) hipLaunchKernelGGL((lin_kernel<KS, MB, OUT_GELU, true>), grid, block, 0, st, LIN_LEAD(a), a);   \
+        else if (a.rsum) hipLaunchKernelGGL((lin_kernel<KS, MB, OUT_NONE, true>), grid, block, 0, st, LIN_LEAD(a), a);                     \
+        else if (out_act == OUT_GELU) hipLaunchKernelGGL((lin_kernel<KS, MB, OUT_GELU, false>), grid, block, 0, st, LIN_LEAD(a), a);       \
+        else if (out_act == OUT_SWISH) hipLaunchKernelGGL((lin_kernel<KS, MB, OUT_SWISH, false>), grid, block, 0, st, LIN_LEAD(a), a);     \
+        else if (out_act == OUT_LRELU) hipLaunchKernelGGL((lin_kernel<KS, MB, OUT_LRELU, false>), grid, block, 0, st, LIN_LEAD(a), a);     \
+        else hipLaunchKernelGGL((lin_kernel<KS, MB, OUT_NONE, false>), grid, block, 0, st, LIN_LEAD(a), a);                                \
     } while (0)
     if (blocks == 1) S3_LIN_LAUNCH(4, 1);
     else if (ks == 8) S3_LIN_LAUNCH(8, 2);
@@ -645,6 +658,7 @@ int launch_lin(const LinArgs& a, int out_act, int rows, hipStream_t st) {
     else if (ks == 2) S3_LIN_LAUNCH(2, 2);
     else S3_LIN_LAUNCH(1, 2);
 #undef S3_LIN_LAUNCH
+#undef LIN_LEAD
     S3_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -667,9 +681,9 @@ int launch_attn(const AttnArgs& a, hipStream_t st) {
     }
     if (force >= 1 && force <= 3) best = force;
     const dim3 grid((tiles + best - 1) / best * a.rows * kHeads);
-    if (best == 1) hipLaunchKernelGGL(attn_kernel<1>, grid, dim3(256), 0, st, a);
-    else if (best == 2) hipLaunchKernelGGL(attn_kernel<2>, grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(attn_kernel<3>, grid, dim3(256), 0, st, a);
+    if (best == 1) hipLaunchKernelGGL(attn_kernel<1>, grid, dim3(256), 0, st, a.q, a.k, a.vt, a.qk_bs, a.vt_bs, a.ld, a.L, a.rows, a);
+    else if (best == 2) hipLaunchKernelGGL(attn_kernel<2>, grid, dim3(256), 0, st, a.q, a.k, a.vt, a.qk_bs, a.vt_bs, a.ld, a.L, a.rows, a);
+    else hipLaunchKernelGGL(attn_kernel<3>, grid, dim3(256), 0, st, a.q, a.k, a.vt, a.qk_bs, a.vt_bs, a.ld, a.L, a.rows, a);
     S3_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -14,7 +14,6 @@ from typing import Any, Dict, List, Optional, Union
 
 import torch
 
-from .config import T3ModelConfig
 from .text_utils import SUPPORTED_LANGUAGES, punc_norm
 from .tts import ChatterboxTTS, REPO_ID
 

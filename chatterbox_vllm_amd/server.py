@@ -25,7 +25,6 @@ import threading
 import wave
 from typing import Any, Dict, Iterator, List, Optional
 
-import numpy as np
 import torch
 
 # ---- text chunking ---------------------------------------------------------------------------------------------------

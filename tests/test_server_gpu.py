@@ -61,3 +61,33 @@ def test_streamed_request_equals_chunk_by_chunk_generate_calls(monkeypatch):
             assert w.getframerate() == 24000 and w.getnframes() == whole.shape[1]
         assert client.post("/v1/audio/speech", json={"input": "x", "language_id": "fr"}).status_code == 400
     svc.shutdown()
+
+
+def test_multilingual_service_detects_the_language_and_streams_the_same_waveforms(monkeypatch):
+    """The multilingual engine behind the service: a request without language_id gets the script-based guess
+    (openai_tts_server.py:406-411), every chunk carries the "[zh]" tag and tokenization hint (mtl_tts.py:419-435), and the
+    streamed waveforms equal one ``generate(chunk, language_id="zh")`` call per chunk."""
+    from chatterbox_vllm_amd.mtl_tts import ChatterboxMultilingualTTS
+    monkeypatch.setenv("CHATTERBOX_DETERMINISTIC", "1")
+    monkeypatch.setenv("CHATTERBOX_CFG_SCALE", "0.5")
+    torch.manual_seed(12)
+    seen = []
+
+    def tok(prompt, language_id=None, **kw):
+        seen.append((prompt, language_id))
+        body = prompt.replace("[START]", "").replace("[STOP]", "")
+        return [255] + [3 + (ord(c) * 11) % 2400 for c in body] + [0]       # ids up to the multilingual vocabulary's range
+    tts = ChatterboxMultilingualTTS.from_synthetic(tokenizer=tok, n_layers=2, max_model_len=400, max_batch_size=4,
+                                                   with_s3gen=True)
+    svc = S.SpeechService(tts)
+    text = "你好，世界。今天天气很好！我们去公园散步吧；然后去吃午饭、喝茶。"
+    chunks = S.plan_chunks(text, 10, 40)
+    assert len(chunks) >= 2
+    got = list(svc.stream_waveforms(text, language_id="", temperature=0.4, diffusion_steps=2, first_chunk_diff_steps=2,
+                                    first_chunk_chars=10, chunk_chars=40))
+    assert len(got) == len(chunks)
+    assert all(p.startswith("[zh][START]") and lang == "zh" for p, lang in seen)
+    for chunk, wav in zip(chunks, got):
+        want = tts.generate(chunk, language_id="zh", temperature=0.4, max_tokens=tts.max_model_len, diffusion_steps=2)[0]
+        assert torch.equal(wav, S.tail_ramp(want, 24000)) and wav.shape[1] > 0
+    svc.shutdown()

@@ -11,7 +11,8 @@ before this process has made any GPU call) and relays rank 0's line.
 One STEP = one pass of the whole hot path over one batch of synthetic requests: the
 154-chunk job of the reference's benchmark.py (text-length histogram of
 docs/benchmark-text-1.txt, tests/golden/ref_text_fixture.json) is queued on one engine with 32
-requests decoded concurrently (the queue is admitted longest request first; --policy fcfs for arrival order),
+requests decoded concurrently (the queue is admitted longest PROMPT first, a ranking by what a caller knows;
+--policy fcfs for arrival order, --policy longest_first for the ranking that also reads each request's max_tokens),
 CFG-paired (cond + uncond stream, scale 3.0), greedy, repetition
 penalty 2.0, prompt + output <= max_model_len 1000.  Random weights never emit the stop token
 reliably, so every request runs to a fixed output length proportional to its text length with
@@ -26,7 +27,9 @@ Other configurations of the same engine:
   --quantization int8       W8A16 backbone weights; with --concurrency 128 --repeat-job 2 the int8 / batch-128 case
 On one GPU the default command also runs them as short extra legs (one timed pass each) and reports them under
 "other_configs", each with its own roofline object; so does the headline job under first-come-first-served admission
-("fcfs_value") and with the uncond row that gets no attention ("uncond_no_attention_value").
+("fcfs_value"), ranked by prompt + max_tokens ("oracle_length_value": max_tokens is each request's exact output length
+here, so this order knows what no caller knows) and with the uncond row that gets no attention
+("uncond_no_attention_value").
 
 Besides the throughput line this prints, in the same JSON object:
   roofline      the dominant kernel's algorithmic bytes / its HIP-event time, measured in a
@@ -217,6 +220,14 @@ def roofline_of(eng, job, conds, use_pmc):
     return roof, breakdown
 
 
+ADMISSION_TEXT = {
+    "fcfs": "fcfs: arrival order (vLLM's policy)",
+    "longest_prompt_first": "longest_prompt_first: the whole queue is known up front (one generate() call) and ranked by "
+                            "prompt length alone; the scheduler never reads max_tokens or the output length",
+    "longest_first": "longest_first: ranked by prompt + max_tokens, and this job sets max_tokens to each request's exact "
+                     "output length: knowledge a caller does not have"}
+
+
 def workload_text(workload, conc):
     return {
         "benchmark": "benchmark.py 154-chunk job (docs/benchmark-text-1.txt length histogram), "
@@ -347,7 +358,7 @@ def flow_decoder_leg(device, frames=1000, n_timesteps=10, iters=3, per_call=8):
     rec = {"workload": f"S3Gen flow-matching decoder, one utterance of {frames} mel frames ({frames * 0.02:.0f} s), {n_timesteps} Euler steps "
                        "x 2 guidance rows, seeded synthetic weights",
            "metric": "audio seconds per second", "value": round(frames * 0.02 / wall, 1), "unit": "audio s/s",
-           "ms_per_step": round(wall * 1e3, 3), "dtype": "f32", "parity": "restatement unpinned (oracle/cfm_oracle.py)",
+           "ms_per_step": round(wall * 1e3, 3), "dtype": "f32", "parity": "restatement pinned by outputs of the reference's decoder.py / flow_matching.py (tests/golden/cfm_fixture.npz); the inside of three diffusers classes unpinned",
            "roofline": {"bound": "mfma", "kernel": "lin_kernel + attn_kernel (about 3 700 launches of a solve)", "achieved": round(achieved, 2),
                         "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
                         "traffic": None, "event_ms_per_call": round(ev_ms, 3), "algorithmic_gflop_per_call": round(flop / 1e9, 1)}}
@@ -403,21 +414,19 @@ def token_to_waveform_leg(device, prompt_tokens=250, new_tokens=250, iters=3):
             "stage_ms": {"flow_encoder": round(stage["flow_encoder"] * 1e3, 2),
                          "flow_decoder": round((stage["flow_decoder_and_encoder"] - stage["flow_encoder"]) * 1e3, 2),
                          "vocoder_and_trim": round((stage["whole"] - stage["flow_decoder_and_encoder"]) * 1e3, 2)},
-            "parity": "flow decoder restatement unpinned; encoder and vocoder pinned by reference outputs"}
+            "parity": "encoder, flow decoder and vocoder pinned by reference outputs (flow decoder: the inside of three diffusers classes unpinned)"}
 
 
-def s3gen_job_leg(device, lengths, prompt_tokens=250, variants=((1, 1), (3, 1), (1, 8), (2, 4))):
+def s3gen_job_leg(device, lengths, prompt_tokens=250, variants=((2, 4), (1, 1), (1, 8), (3, 4))):
     """The second half of the reference's benchmark.py for the same job: every chunk's speech tokens through the token ->
     waveform chain with a 10 s voice prompt.  The token counts are the ones the T3 leg generated for the job's chunks; the
-    token values and all weights are seeded synthetic.  `value` is with one utterance at a time, as the reference runs it
-    (tts.py:428-557).  `variants` repeats the job as (utterances in flight, utterances per call): several utterances in
-    flight, each on its own chain (weights, workspace, stream, host thread), use the CUs that the launches of one 20 s
-    utterance leave idle; several chunks of similar length per call (S3Token2Wav.inference_batch) share the flow-matching
-    stage's launches, which fills the CUs inside each launch instead; chunks are handed out longest first.  Reported beside
-    the T3 time so that the whole text -> waveform job has a number (the reference's README reports the two times for its
-    run, README.md:150-153)."""
-    import queue
-    import threading
+    token values and all weights are seeded synthetic.  `variants` are (copies of the chain in flight, utterances per
+    call), all through S3Token2Wav.render_many: several chunks of similar length per call share the flow-matching stage's
+    launches, several copies (each with its own weights, workspace, stream and host thread) use the CUs that one copy's
+    launches leave idle; chunks are handed out longest first.  `value` is the FIRST variant, (2, 4): the schedule the
+    facade builds by default (ChatterboxTTS.from_local / from_synthetic).  (1, 1) is one utterance at a time, as the
+    reference runs it (tts.py:428-557).  Reported beside the T3 time so that the whole text -> waveform job has a number
+    (the reference's README reports the two times for its run, README.md:150-153)."""
     from chatterbox_vllm_amd import cfm_weights as CW, flow_weights as FW, hift_weights as HW
     from chatterbox_vllm_amd.s3gen import S3Token2Wav
     flow_sd = dict(FW.synthetic_state_dict())
@@ -430,55 +439,29 @@ def s3gen_job_leg(device, lengths, prompt_tokens=250, variants=((1, 1), (3, 1), 
            "prompt_feat": (2.0 * torch.randn(1, 2 * prompt_tokens, 80, generator=g) - 4.0).to(dev),
            "embedding": torch.randn(1, 192, generator=g).to(dev)}
     toks = [torch.randint(0, 6561, (n,), generator=g).to(dev) for n in lengths]
-    order = sorted(range(len(toks)), key=lambda i: -lengths[i])
+    longest = sorted(range(len(toks)), key=lambda i: -lengths[i])
     runs = []
     for nw, nb in variants:
-        chains = [S3Token2Wav(flow_sd, hift_sd, max_tokens=prompt_tokens + max(lengths), device=device, max_batch=nb) for _ in range(nw)]
-        streams = [torch.cuda.Stream(device=dev) for _ in range(nw)]
-
-        def run_group(w, group):
-            if nb == 1:
-                return chains[w].inference(toks[group[0]], ref)[0].shape[1]
-            return sum(wav.shape[1] for wav in chains[w].inference_batch([toks[i] for i in group], ref))
-
-        for w in range(nw):
-            with torch.cuda.stream(streams[w]):
-                run_group(w, order[:nb])
+        s3 = S3Token2Wav(flow_sd, hift_sd, max_tokens=prompt_tokens + max(lengths), device=device, max_batch=nb, chains=nw)
+        s3.render_many([toks[i] for i in longest[:2 * nw * nb]], ref)          # warm-up of every copy
         torch.cuda.synchronize(device)
-        q = queue.Queue()
-        for j in range(0, len(order), nb):
-            q.put(order[j:j + nb])
-        samples = [0] * nw
-
-        def work(w):
-            with torch.cuda.stream(streams[w]):
-                while True:
-                    try:
-                        group = q.get_nowait()
-                    except queue.Empty:
-                        break
-                    samples[w] += run_group(w, group)
-                streams[w].synchronize()
-
         t0 = time.perf_counter()
-        threads = [threading.Thread(target=work, args=(w,)) for w in range(nw)]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
+        wavs = s3.render_many(toks, ref)
         torch.cuda.synchronize(device)
         dt = time.perf_counter() - t0
-        for c in chains:
-            c.shutdown()
+        samples = sum(w.shape[1] for w in wavs)
+        s3.shutdown()
         runs.append({"utterances_in_flight": nw, "utterances_per_call": nb, "seconds": round(dt, 3),
-                     "value": round(sum(samples) / 24000 / dt, 1), "audio_seconds": round(sum(samples) / 24000, 1)})
+                     "value": round(samples / 24000 / dt, 1), "audio_seconds": round(samples / 24000, 1)})
     first = runs[0]
     rec = {"workload": f"S3Gen over the job's {len(lengths)} chunks ({sum(lengths)} speech tokens, {min(lengths)}-{max(lengths)} per chunk), "
                        f"{prompt_tokens}-token voice prompt, 10 Euler steps, seeded synthetic weights",
            "metric": "generated audio seconds per second", "value": first["value"], "unit": "audio s/s",
+           "schedule": "the facade's default: two copies of the chain, four utterances per call, longest first",
            "utterances_in_flight": first["utterances_in_flight"], "utterances_per_call": first["utterances_per_call"],
            "seconds": first["seconds"], "audio_seconds": first["audio_seconds"], "dtype": "f32"}
     rec["variants"] = [{k: v for k, v in r.items() if k != "audio_seconds"} for r in runs[1:]]
+    rec["one_utterance_at_a_time_seconds"] = next((r["seconds"] for r in runs if (r["utterances_in_flight"], r["utterances_per_call"]) == (1, 1)), None)
     return rec
 
 
@@ -514,14 +497,35 @@ def extra_leg(args, device, sd_cache, workload, conc, quantization, repeat, labe
     return rec
 
 
+def visible_gpu_count():
+    """GPUs this process may use, counted without any HIP or torch.cuda call (the parent of the ranks must not
+    initialise the GPU): the compute nodes of /sys/class/kfd/kfd/topology/nodes that have SIMDs, cut down by
+    ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES when one of them lists devices.  None when the
+    topology cannot be read: the ranks then find out themselves."""
+    nodes = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        n = 0
+        for d in os.listdir(nodes):
+            with open(os.path.join(nodes, d, "properties")) as fh:
+                props = dict(ln.split()[:2] for ln in fh if len(ln.split()) >= 2)
+            n += int(props.get("simd_count", "0")) > 0
+    except (OSError, ValueError):
+        return None
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip()]))
+    return n
+
+
 def launch_ranks(args) -> int:
     """`bench.py --gpus N` from a plain shell: start N ranks as ONE child process (torch.distributed.run) and pass its
     exit code on.  Called before this process has made any GPU call; this process only waits."""
     import socket
     import subprocess
     if args.backend == "nccl" and not args.rehearse:
-        n = torch.cuda.device_count()                      # counts devices without initialising the GPU
-        if n < args.gpus:
+        n = visible_gpu_count()
+        if n is not None and n < args.gpus:
             print(f"bench.py: --gpus {args.gpus} needs {args.gpus} GPUs, {n} visible "
                   "(--backend gloo lets ranks share a GPU to rehearse the multi-rank path)", file=sys.stderr)
             return 2
@@ -580,10 +584,12 @@ def main():
     ap.add_argument("--concurrency", type=int, default=0, help="requests decoded together per job (default 32; single: 1)")
     ap.add_argument("--quantization", choices=["none", "int8"], default="none")
     ap.add_argument("--repeat-job", type=int, default=1, help="queue the request list this many times per step")
-    ap.add_argument("--policy", choices=["fcfs", "longest_first"], default="longest_first",
-                    help="admission order of the queue: longest request first keeps the 32 slots full until the queue "
-                         "is nearly dry (mean 31 of 32 slots busy against 26 with first come first served); "
-                         "token ids are the same under both")
+    ap.add_argument("--policy", choices=["fcfs", "longest_prompt_first", "longest_first"], default="longest_prompt_first",
+                    help="admission order of the queue.  longest_prompt_first (default) ranks the waiting requests by "
+                         "prompt length alone, which every caller knows; it keeps the 32 slots full until the queue is "
+                         "nearly dry.  fcfs is vLLM's order.  longest_first also reads max_tokens, which this job sets "
+                         "to each request's exact output length: a ranking with knowledge a caller does not have, "
+                         "reported as an extra.  Token ids are the same under all three")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: every rank runs the whole job with all the slots.  strong: ONE job is dealt round-robin "
                          "over the ranks and the slots are divided among them (config 4: 128 slots / N)")
@@ -629,6 +635,8 @@ def main():
             local_rank %= max(1, torch.cuda.device_count())
             dist.init_process_group("gloo")
         else:
+            if local_rank >= torch.cuda.device_count():
+                sys.exit(f"bench.py: rank {rank} needs GPU {local_rank}, {torch.cuda.device_count()} visible")
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if world != args.gpus:
@@ -706,7 +714,7 @@ def main():
             "config": {"workload": workload_text(args.workload, conc),
                        "requests_per_gpu": len(job), "tokens_per_step_per_gpu": tokens // max(1, args.steps),
                        "concurrency": conc, "layers": cfg.n_layers, "weights": "int8 (W8A16)" if args.quantization == "int8" else "bf16",
-                       "admission": args.policy, "uncond_stream": "no attention, no KV" if args.uncond_no_attention else "own KV",
+                       "admission": ADMISSION_TEXT[args.policy], "uncond_stream": "no attention, no KV" if args.uncond_no_attention else "own KV",
                        "cond_prefix_kv": "per stream" if args.no_prefix_sharing else "shared per voice",
                        "parallelism": f"request-sharded x{world}"},
             "per_gpu_tokens_per_s": round(total_tokens / dt / world, 2),
@@ -724,15 +732,19 @@ def main():
     # ---- the same job under the admission order vLLM has (first come first served), driver-timed like the headline
     extras = rank == 0 and world == 1 and not args.no_extra_legs and not args.rehearse and args.workload == "benchmark" \
         and args.quantization == "none" and not args.uncond_no_attention
-    if extras and args.policy != "fcfs":
-        eng.set_schedule_policy("fcfs")
-        run_job(eng, job, conds)
-        torch.cuda.synchronize(local_rank)
-        t1 = time.perf_counter()
-        n_f, ids_f = run_job(eng, job, conds)
-        torch.cuda.synchronize(local_rank)
-        result["fcfs_value"] = round(n_f / (time.perf_counter() - t1), 2)
-        result["fcfs_ids_equal"] = ids_f == last_ids
+    if extras:
+        for pol, key in (("fcfs", "fcfs_value"), ("longest_first", "oracle_length_value")):
+            if pol == args.policy:
+                continue
+            eng.set_schedule_policy(pol)
+            run_job(eng, job, conds)
+            torch.cuda.synchronize(local_rank)
+            t1 = time.perf_counter()
+            n_f, ids_f = run_job(eng, job, conds)
+            torch.cuda.synchronize(local_rank)
+            result[key] = round(n_f / (time.perf_counter() - t1), 2)
+            result[key.replace("value", "ids_equal")] = ids_f == last_ids
+        result["oracle_length_note"] = ADMISSION_TEXT["longest_first"]
     eng.shutdown()
 
     if extras:

@@ -101,6 +101,7 @@ SIGNATURES = {
     "t3_op_gemm": ([_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P], C.c_int),
     "t3_op_gemm_slab": ([_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P], C.c_int),
     "t3_op_slab_split": ([], C.c_int),
+    "t3_op_set_prompt_gemm_form": ([C.c_int32], C.c_int),
     "t3_op_slab_add_rmsnorm": ([_P, C.c_int32, _P, _P, _P, C.c_int32, C.c_int32, C.c_float, _P], C.c_int),
     "t3_op_slab_add_rmsnorm_tiled": ([_P, C.c_int32, _P, _P, _P, C.c_int32, C.c_int32, C.c_float, _P], C.c_int),
     "t3_op_gemm_silu": ([_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P], C.c_int),

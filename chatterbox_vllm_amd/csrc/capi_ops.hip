@@ -54,6 +54,8 @@ extern "C" int t3_op_gemm_prompt_slab(const void* a_dev, const void* wt_dev, flo
 }
 
 extern "C" int t3_op_slab_split(void) { return GEMM_SLAB_SPLIT; }
+void set_prompt_gemm_form(int walk);
+extern "C" int t3_op_set_prompt_gemm_form(int32_t walk) { set_prompt_gemm_form(walk); return 0; }
 
 extern "C" int t3_op_slab_add_rmsnorm(const float* slab_dev, int32_t nsplit, void* res_dev, const void* w_dev, void* xn_dev,
                                       int32_t rows, int32_t d, float eps, void* stream) {
@@ -283,8 +285,12 @@ static int attn_prefill_op(const void* qkv_dev, void* out_dev, int32_t n_seqs, c
 #define T3_STATIC_SEQS_MAX 1024        // sequences per call
 static __device__ __align__(256) int32_t scratch[2 * T3_STATIC_TILES_MAX];
 
+// Writes exactly `ntiles` (sequence, first query row) pairs, the number the host sized the launch for from ITS copy of
+// seq_start.  Should the device copy disagree (a stale upload), tiles past `ntiles` are dropped instead of written
+// behind the array, and pairs the device copy does not produce are filled with (0, 0), a valid tile of sequence 0, so
+// the attention launch never reads a pair this call did not write.
 __global__ __launch_bounds__(256) void build_prefill_tiles_kernel(const int32_t* __restrict__ seq_start, int n_seqs,
-                                                                  int32_t* __restrict__ tiles) {
+                                                                  int32_t* __restrict__ tiles, int ntiles) {
     __shared__ int32_t first_tile[T3_STATIC_SEQS_MAX + 1];
     for (int i = threadIdx.x; i < n_seqs; i += 256) first_tile[i + 1] = (seq_start[i + 1] - seq_start[i] + 63) >> 6;
     __syncthreads();
@@ -294,7 +300,9 @@ __global__ __launch_bounds__(256) void build_prefill_tiles_kernel(const int32_t*
     }
     __syncthreads();
     for (int i = threadIdx.x; i < n_seqs; i += 256)
-        for (int t = first_tile[i], q0 = 0; t < first_tile[i + 1]; ++t, q0 += 64) { tiles[2 * t] = i; tiles[2 * t + 1] = q0; }
+        for (int t = first_tile[i], q0 = 0; t < first_tile[i + 1]; ++t, q0 += 64)
+            if (t < ntiles) { tiles[2 * t] = i; tiles[2 * t + 1] = q0; }
+    for (int t = first_tile[n_seqs] + (int)threadIdx.x; t < ntiles; t += 256) { tiles[2 * t] = 0; tiles[2 * t + 1] = 0; }
 }
 
 static int32_t* g_scratch_ptr[T3_MAX_DEVICES];           // address of `scratch` on each device, looked up on first use
@@ -327,9 +335,16 @@ extern "C" int t3_op_attn_prefill_static(const void* qkv_dev, void* out_dev, int
     T3_REQUIRE(ntiles <= T3_STATIC_TILES_MAX,
                "attn_prefill_static: more than 4096 query tiles (sum of ceil(rows / 64)); use t3_op_attn_prefill");
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (st) {                                            // the array used is the current device's: the stream must live there
+        hipDevice_t sdev = -1;
+        int cur = -1;
+        T3_HIP_CHECK(hipStreamGetDevice(st, &sdev));
+        T3_HIP_CHECK(hipGetDevice(&cur));
+        T3_REQUIRE((int)sdev == cur, "attn_prefill_static: the stream belongs to another device than the current one");
+    }
     int32_t* tiles = nullptr;
     if (scratch_of_current_device(&tiles)) return 1;
-    T3_LAUNCH(build_prefill_tiles_kernel, dim3(1), dim3(256), 0, st, seq_start_dev, n_seqs, tiles);
+    T3_LAUNCH(build_prefill_tiles_kernel, dim3(1), dim3(256), 0, st, seq_start_dev, n_seqs, tiles, (int)ntiles);
     T3_HIP_CHECK(hipGetLastError());
     return launch_attn_prefill(static_cast<const bf16_t*>(qkv_dev), 3 * H * hd, static_cast<bf16_t*>(out_dev), seq_start_dev,
                                tiles, (int)ntiles, H, hd, st, nullptr, 0, nullptr, 0);

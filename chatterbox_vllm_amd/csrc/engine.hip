@@ -237,7 +237,7 @@ struct t3_engine {
     bool async_steps = true;
 
     std::deque<std::unique_ptr<Request>> waiting;
-    int schedule_policy = 0;                            // 0: first come first served; 1: longest expected request first
+    int schedule_policy = 0;                            // 0: first come first served; 1: longest prompt + max_tokens first; 2: longest prompt first
     std::vector<std::unique_ptr<Request>> slots;
 
     std::unordered_map<int, hipGraphExec_t> graphs;
@@ -1077,12 +1077,15 @@ extern "C" int t3_engine_add_request(t3_engine* e, int64_t req_id, const int32_t
     r->prompt_len = P;
     r->limit = std::max(1, std::min(sp->max_tokens, c.max_model_len - P));
     r->reserve_pages = pages_for(std::min(P + sp->max_tokens, c.max_model_len));
-    if (e->schedule_policy == 1) {
+    if (e->schedule_policy != 0) {
         // longest first: a queue that is known up front drains with fewer half-empty steps at its end.  Stable
-        // for equal sizes; which requests share a step never changes a request's tokens.
-        const int work = r->prompt_len + r->limit;
+        // for equal sizes; which requests share a step never changes a request's tokens.  Policy 2 ranks by the
+        // prompt alone (what a caller knows: longer text, longer speech); policy 1 also reads max_tokens, which is
+        // a ranking by true length only when the caller sets max_tokens per request to the length it expects.
+        auto work = [&](const Request& q) { return e->schedule_policy == 2 ? q.prompt_len : q.prompt_len + q.limit; };
+        const int mine = work(*r);
         auto it = e->waiting.begin();
-        while (it != e->waiting.end() && (*it)->prompt_len + (*it)->limit >= work) ++it;
+        while (it != e->waiting.end() && work(**it) >= mine) ++it;
         e->waiting.insert(it, std::move(r));
     } else {
         e->waiting.push_back(std::move(r));
@@ -1092,7 +1095,8 @@ extern "C" int t3_engine_add_request(t3_engine* e, int64_t req_id, const int32_t
 
 extern "C" int t3_engine_set_schedule_policy(t3_engine* e, int32_t policy) {
     T3_REQUIRE(e, "null argument");
-    T3_REQUIRE(policy == 0 || policy == 1, "policy must be 0 (first come first served) or 1 (longest first)");
+    T3_REQUIRE(policy >= 0 && policy <= 2,
+               "policy must be 0 (first come first served), 1 (longest prompt + max_tokens first) or 2 (longest prompt first)");
     e->schedule_policy = policy;
     return 0;
 }

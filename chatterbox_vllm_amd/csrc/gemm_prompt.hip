@@ -28,6 +28,7 @@
 // columns), EPI_SLAB (split-K 8 fp32 partials for o_proj / down_proj, summed by the norm kernel).
 #include "t3_common.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -52,6 +53,75 @@ __device__ __forceinline__ bf16x8 prompt_dequant8(unsigned lo, unsigned hi) {
 template <int V> using IC = std::integral_constant<int, V>;
 
 }  // namespace
+
+// Epilogue of one 16-row x 64-column accumulator tile: lane holds columns 4*(lane>>4)..+3 of n-block `ni` (acc[ni]) of row r.
+template <int EPI, class NbOf>
+__device__ __forceinline__ void prompt_store_tile(const GemmArgs& a, const f32x4 (&acc)[4], int r, int z, int n_tile, int region,
+                                                  int head, int H, NbOf nb_of, int lane) {
+    const int nl = 4 * (lane >> 4);
+    if (r >= a.M) return;
+    if constexpr (EPI == EPI_SLAB) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+            *reinterpret_cast<f32x4*>(a.slab + ((size_t)z * a.M + r) * a.N + nb_of(ni) * 16 + nl) = acc[ni];
+    } else if constexpr (EPI == EPI_SILU) {
+        const int F = a.N >> 1;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            float hv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float g = rbf(acc[ni][i]), u = rbf(acc[ni + 2][i]);
+                const float sg = rbf(g / (1.0f + expf(-g)));
+                hv[i] = sg * u;
+            }
+            const u32x2 o = {pack_bf2(hv[0], hv[1]), pack_bf2(hv[2], hv[3])};
+            *reinterpret_cast<u32x2*>(a.C + (size_t)r * F + (n_tile * 2 + ni) * 16 + nl) = o;
+        }
+    } else {   // EPI_QKV_ROPE: this tile's 64 columns are head `head` of q, k or v
+        const int hd = 64, D = H * hd;
+        const int pos = a.pos[r];
+        bf16_t* qrow = a.C + (size_t)r * a.ldc + region * D + head * hd;
+        bf16_t* kvrow = nullptr;
+        if (region >= 1) {
+            const int st = a.row_stream[r];
+            if (st >= 0) {
+                const int page = a.kv.block_table[(size_t)st * a.kv.max_pages + (pos >> 6)];
+                kvrow = a.kv.pool + (size_t)a.layer * a.kv.layer_stride +
+                        ((size_t)page * 2 + (region - 1)) * ((size_t)H * T3_PAGE * hd) +
+                        ((size_t)head * T3_PAGE + (pos & 63)) * hd;
+            }
+        }
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int c0 = ni * 16 + nl, c1 = c0 + 32;
+            float x[4], y[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { x[i] = rbf(acc[ni][i]); y[i] = rbf(acc[ni + 2][i]); }
+            if (region < 2) {
+                const bf16_t* tb = a.rope + (size_t)pos * hd;
+                const u32x2 cs = *reinterpret_cast<const u32x2*>(tb + c0);
+                const u32x2 sn = *reinterpret_cast<const u32x2*>(tb + 32 + c0);
+                const float c[4] = {bf_lo(cs[0]), bf_hi(cs[0]), bf_lo(cs[1]), bf_hi(cs[1])};
+                const float sv[4] = {bf_lo(sn[0]), bf_hi(sn[0]), bf_lo(sn[1]), bf_hi(sn[1])};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float xr = x[i] * c[i] - y[i] * sv[i];
+                    const float yr = y[i] * c[i] + x[i] * sv[i];
+                    x[i] = xr; y[i] = yr;
+                }
+            }
+            const u32x2 ox = {pack_bf2(x[0], x[1]), pack_bf2(x[2], x[3])};
+            const u32x2 oy = {pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3])};
+            *reinterpret_cast<u32x2*>(qrow + c0) = ox;
+            *reinterpret_cast<u32x2*>(qrow + c1) = oy;
+            if (kvrow) {
+                *reinterpret_cast<u32x2*>(kvrow + c0) = ox;
+                *reinterpret_cast<u32x2*>(kvrow + c1) = oy;
+            }
+        }
+    }
+}
 
 template <int EPI, bool W8>
 __global__ __launch_bounds__(256) void gemm_prompt_kernel(
@@ -218,77 +288,174 @@ __global__ __launch_bounds__(256) void gemm_prompt_kernel(
     }
 
     // ---- epilogue: lane holds columns 4*(lane>>4)..+3 of n-block `ni`, row (lane & 15) of row tile `mi`
-    const int nl = 4 * (lane >> 4);
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-        const int r = m0 + w * 32 + mi * 16 + (lane & 15);
-        if (r >= a.M) continue;
-        if constexpr (EPI == EPI_SLAB) {
+    for (int mi = 0; mi < 2; ++mi)
+        prompt_store_tile<EPI>(a, acc[mi], m0 + w * 32 + mi * 16 + (lane & 15), z, n_tile, region, head, H, nb_of, lane);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Row-walking form: every weight byte is fetched ONCE per launch (per 512 rows).
+//
+// gemm_prompt_kernel gives every 128-row tile of a 64-column weight tile a workgroup of its own; the five or six of them
+// ask for the same weight lines at the same time, the L2 does not merge those misses, and the launch fetches its weights
+// four times over (counters: gate_up 66.6 MB for 16.8 MB of weights).  Here ONE workgroup owns the 64 columns (and its K
+// range) and walks ALL rows with them: 4 waves x 128 rows, a wave's 8 x 4 accumulator tiles (128 VGPRs) stay in registers
+// for the whole K loop.  K advances in steps of 32.  The W block of a step (4 n-blocks x 1 KiB in the global tile order)
+// goes through a two-stage LDS ring and is read by all four waves.  The A rows belong to one wave each, so staging them in
+// LDS would only add a write and a read per byte (that version was LDS-bound at 1.1 us per step): a wave loads its 8 MFMA
+// B fragments of a step straight from memory (lane = row, 16 bytes = 8 k) three steps ahead, in registers.  The
+// accumulation order of an output is k order inside one accumulator, as in gemm_prompt_kernel: the same bits.
+// Fewer, longer workgroups (gate_up: 128 instead of 640) leave CUs to the decode stream that runs beside a prefill job;
+// the launch itself takes 1.5 to 3 times as long as gemm_prompt_kernel's at a few hundred rows (equal at 4096), so the
+// engine does not use this form by default (see g_prompt_walk below).
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int WBM = 512;                             // rows per workgroup: 4 waves x 8 row tiles of 16
+constexpr int WW_ELEMS = 4 * 512;                    // 4 n-blocks x one 16 x 32 tile = 4 KiB
+constexpr int WAD = 3;                               // k-steps of A fragments in flight per wave
+}  // namespace
+
+template <int EPI, bool W8>
+__global__ __launch_bounds__(256, 1) void gemm_prompt_walk_kernel(
+        int m_groups, int n_tiles, int ksplit, const bf16_t* lead_A, const bf16_t* lead_Wt, int lead_M, int lead_N,
+        int lead_K, int lead_lda, int lead_H, GemmArgs a_) {
+    GemmArgs a = a_;
+    a.A = lead_A; a.Wt = lead_Wt; a.M = lead_M; a.N = lead_N; a.K = lead_K; a.lda = lead_lda; a.kv.H = lead_H;
+    __shared__ __attribute__((aligned(16))) bf16_t wlds[2][WW_ELEMS];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const int t = blockIdx.x;
+    const int m_group = t % m_groups;
+    const int rest = t / m_groups;
+    const int n_tile = rest % n_tiles;
+    const int z = rest / n_tiles;
+    const int g0 = m_group * WBM;
+    const int ktiles = a.K >> 5;
+    const int kspan = a.K / ksplit;
+    const int k0 = z * kspan;
+    const int nks = kspan >> 5;                       // k-steps of 32; a multiple of 3 * 4 is not required, see the loop
+
+    int H = 0, region = 0, head = 0;
+    if constexpr (EPI == EPI_QKV_ROPE) {
+        H = a.kv.H;
+        region = n_tile / H;
+        head = n_tile - region * H;
+    }
+    auto nb_of = [&](int s) -> int {
+        if constexpr (EPI == EPI_SILU) return n_tile * 2 + (s & 1) + (s >> 1) * (a.N >> 5);
+        else if constexpr (EPI == EPI_QKV_ROPE) return region * 4 * H + head * 4 + s;
+        else return n_tile * 4 + s;
+    };
+
+    // A fragment of row tile mi: lane (row = lane & 15, k group = lane >> 4) holds 8 consecutive k of its row
+    const bf16_t* ag[8];
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+        int r = g0 + w * 128 + mi * 16 + (lane & 15);
+        r = r < a.M ? r : a.M - 1;
+        ag[mi] = a.A + (size_t)r * a.lda + k0 + 8 * (lane >> 4);
+    }
+    // W: one 16-byte unit per thread and k-step (bf16), or per pair of k-steps (int8 pair tiles)
+    const int w_slot = tid >> 6;
+    const bf16_t* wg = W8 ? a.Wt + (((size_t)nb_of(w_slot) * (ktiles >> 1) + (k0 >> 6)) * 64 + lane) * 8
+                          : a.Wt + ((size_t)nb_of(w_slot) * ktiles + (k0 >> 5)) * 512 + lane * 8;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    u32x4 ra[WAD][8], rw[4];
+    auto issue_a = [&](auto S_, int step) {
+        constexpr int S = decltype(S_)::value;
+        step = step < nks ? step : nks - 1;
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) ra[S][mi] = *reinterpret_cast<const u32x4*>(ag[mi] + step * 32);
+    };
+    auto issue_w = [&](auto S_, int step) {
+        constexpr int S = decltype(S_)::value;
+        step = step < nks ? step : nks - 1;
+        if constexpr (W8) rw[S] = *reinterpret_cast<const u32x4*>(wg + (size_t)(step >> 1) * 512);
+        else rw[S] = *reinterpret_cast<const u32x4*>(wg + (size_t)step * 512);
+    };
+    auto stage_w = [&](auto R_, int step) {
+        constexpr int R = decltype(R_)::value;
+        *reinterpret_cast<u32x4*>(&wlds[step & 1][tid * 8]) = rw[R];
+    };
+    auto multiply = [&](auto S_, int step) {
+        constexpr int S = decltype(S_)::value;
+        bf16x8 wf[4];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const u32x4 q = *reinterpret_cast<const u32x4*>(&wlds[step & 1][ni * 512 + lane * 8]);
+            if constexpr (W8) wf[ni] = (step & 1) ? prompt_dequant8(q[2], q[3]) : prompt_dequant8(q[0], q[1]);
+            else wf[ni] = __builtin_bit_cast(bf16x8, q);
+        }
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            const bf16x8 af = __builtin_bit_cast(bf16x8, ra[S][mi]);
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni)
-                *reinterpret_cast<f32x4*>(a.slab + ((size_t)z * a.M + r) * a.N + nb_of(ni) * 16 + nl) = acc[mi][ni];
-        } else if constexpr (EPI == EPI_SILU) {
-            const int F = a.N >> 1;
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af, acc[mi][ni], 0, 0, 0);
+        }
+    };
+    // One k-step with static register indices: the W block of step s + 1 goes to the other LDS stage, step s is multiplied,
+    // the A set and the W slot that step s vacated are refilled (steps s + WAD and s + 4).  12 steps per trip of the
+    // unrolled loop (lcm of the two ring lengths); steps past the end re-read the last step and multiply nothing.
+    auto kstep = [&](auto SA_, auto SW_, int s) {
+        constexpr int SA = decltype(SA_)::value, SW = decltype(SW_)::value;
+        if (s >= nks) return;
+        if (s + 1 < nks) stage_w(IC<(SW + 1) % 4>{}, s + 1);
+        multiply(IC<SA>{}, s);
+        issue_a(IC<SA>{}, s + WAD);
+        issue_w(IC<SW>{}, s + 4);
+        __syncthreads();
+    };
+    issue_w(IC<0>{}, 0); issue_w(IC<1>{}, 1); issue_w(IC<2>{}, 2); issue_w(IC<3>{}, 3);
+    issue_a(IC<0>{}, 0); issue_a(IC<1>{}, 1); issue_a(IC<2>{}, 2);
+    stage_w(IC<0>{}, 0);
+    __syncthreads();
+    for (int s = 0; s < nks; s += 12) {
+        kstep(IC<0>{}, IC<0>{}, s);      kstep(IC<1>{}, IC<1>{}, s + 1);  kstep(IC<2>{}, IC<2>{}, s + 2);
+        kstep(IC<0>{}, IC<3>{}, s + 3);  kstep(IC<1>{}, IC<0>{}, s + 4);  kstep(IC<2>{}, IC<1>{}, s + 5);
+        kstep(IC<0>{}, IC<2>{}, s + 6);  kstep(IC<1>{}, IC<3>{}, s + 7);  kstep(IC<2>{}, IC<0>{}, s + 8);
+        kstep(IC<0>{}, IC<1>{}, s + 9);  kstep(IC<1>{}, IC<2>{}, s + 10); kstep(IC<2>{}, IC<3>{}, s + 11);
+    }
+
+    if constexpr (W8) {
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-                float hv[4];
+        for (int ni = 0; ni < 4; ++ni) {
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(a.wscale + nb_of(ni) * 16 + 4 * (lane >> 4));
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float g = rbf(acc[mi][ni][i]), u = rbf(acc[mi][ni + 2][i]);
-                    const float sg = rbf(g / (1.0f + expf(-g)));
-                    hv[i] = sg * u;
-                }
-                const u32x2 o = {pack_bf2(hv[0], hv[1]), pack_bf2(hv[2], hv[3])};
-                *reinterpret_cast<u32x2*>(a.C + (size_t)r * F + (n_tile * 2 + ni) * 16 + nl) = o;
-            }
-        } else {   // EPI_QKV_ROPE: this tile's 64 columns are head `head` of q, k or v
-            const int hd = 64, D = H * hd;
-            const int pos = a.pos[r];
-            bf16_t* qrow = a.C + (size_t)r * a.ldc + region * D + head * hd;
-            bf16_t* kvrow = nullptr;
-            if (region >= 1) {
-                const int st = a.row_stream[r];
-                if (st >= 0) {
-                    const int page = a.kv.block_table[(size_t)st * a.kv.max_pages + (pos >> 6)];
-                    kvrow = a.kv.pool + (size_t)a.layer * a.kv.layer_stride +
-                            ((size_t)page * 2 + (region - 1)) * ((size_t)H * T3_PAGE * hd) +
-                            ((size_t)head * T3_PAGE + (pos & 63)) * hd;
-                }
-            }
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-                const int c0 = ni * 16 + nl, c1 = c0 + 32;
-                float x[4], y[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { x[i] = rbf(acc[mi][ni][i]); y[i] = rbf(acc[mi][ni + 2][i]); }
-                if (region < 2) {
-                    const bf16_t* tb = a.rope + (size_t)pos * hd;
-                    const u32x2 cs = *reinterpret_cast<const u32x2*>(tb + c0);
-                    const u32x2 sn = *reinterpret_cast<const u32x2*>(tb + 32 + c0);
-                    const float c[4] = {bf_lo(cs[0]), bf_hi(cs[0]), bf_lo(cs[1]), bf_hi(cs[1])};
-                    const float sv[4] = {bf_lo(sn[0]), bf_hi(sn[0]), bf_lo(sn[1]), bf_hi(sn[1])};
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const float xr = x[i] * c[i] - y[i] * sv[i];
-                        const float yr = y[i] * c[i] + x[i] * sv[i];
-                        x[i] = xr; y[i] = yr;
-                    }
-                }
-                const u32x2 ox = {pack_bf2(x[0], x[1]), pack_bf2(x[2], x[3])};
-                const u32x2 oy = {pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3])};
-                *reinterpret_cast<u32x2*>(qrow + c0) = ox;
-                *reinterpret_cast<u32x2*>(qrow + c1) = oy;
-                if (kvrow) {
-                    *reinterpret_cast<u32x2*>(kvrow + c0) = ox;
-                    *reinterpret_cast<u32x2*>(kvrow + c1) = oy;
-                }
-            }
+            for (int mi = 0; mi < 8; ++mi) acc[mi][ni] *= sc;
         }
     }
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+        prompt_store_tile<EPI>(a, acc[mi], g0 + w * 128 + mi * 16 + (lane & 15), z, n_tile, region, head, H, nb_of, lane);
 }
+
+// Which form prompt-row launches take: 0 = one workgroup per 128-row tile (default), 1 = the row-walking kernel.  Both give
+// the same bits; the switch exists for their A/B (T3_PROMPT_WALK=1 in the environment, or t3_op_set_prompt_gemm_form).
+// Measured (1 x MI355X): the row-walking form fetches its weights once instead of four times, but a workgroup's K loop is
+// bound by what one CU's vector memory path pulls (about 32 KB of A rows per microsecond), and with one workgroup per weight
+// tile only 48 to 128 CUs pull: gate_up at 612 rows 39.8 us against 24.0, the benchmark job 19.3k against 19.6k tokens/s.
+static int g_prompt_walk = [] { const char* v = getenv("T3_PROMPT_WALK"); return (v && v[0] == '1') ? 1 : 0; }();
+void set_prompt_gemm_form(int walk) { g_prompt_walk = walk ? 1 : 0; }
+static bool prompt_walk_enabled() { return g_prompt_walk != 0; }
 
 template <int EPI, bool W8>
 static int launch_prompt_w(const GemmArgs& a, int n_tiles, int ksplit, hipStream_t st) {
+    if (prompt_walk_enabled() && (a.K / ksplit) % 64 == 0) {
+        const int m_groups = (a.M + WBM - 1) / WBM;
+        T3_LAUNCH((gemm_prompt_walk_kernel<EPI, W8>), dim3(m_groups * n_tiles * ksplit), dim3(256), 0, st, m_groups, n_tiles,
+                  ksplit, a.A, a.Wt, a.M, a.N, a.K, a.lda, a.kv.H, a);
+        T3_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     constexpr size_t lds = 2 * (size_t)PSTAGE * sizeof(bf16_t);
     const int m_tiles = (a.M + PBM - 1) / PBM;
     const int total = m_tiles * n_tiles * ksplit;

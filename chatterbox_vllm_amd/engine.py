@@ -76,6 +76,9 @@ class RequestOutput:
 _FINISH = {1: "stop", 2: "length", 3: "error"}
 
 
+SCHEDULING_POLICIES = ("fcfs", "longest_first", "longest_prompt_first")     # index = the C ABI's policy number
+
+
 class T3Engine:
     """One engine per GPU.  ``generate`` calls from several threads (the reference's server calls it from
     worker threads without a lock, openai_tts_server.py:501, 661) are serialised here: one call runs its
@@ -129,10 +132,7 @@ class T3Engine:
             _capi.check(self._lib, self._lib.t3_engine_create(C.byref(cfg), C.byref(self._h)))
         else:
             _capi.check(self._lib, self._lib.t3_engine_create_on_stream(C.byref(cfg), C.c_void_p(int(stream)), C.byref(self._h)))
-        if scheduling_policy not in ("fcfs", "longest_first"):
-            raise ValueError("scheduling_policy must be 'fcfs' (vLLM's default) or 'longest_first'")
-        self.scheduling_policy = scheduling_policy
-        _capi.check(self._lib, self._lib.t3_engine_set_schedule_policy(self._h, int(scheduling_policy == "longest_first")))
+        self.set_schedule_policy(scheduling_policy)
         self._next_id = 0
         self._generate_lock = threading.Lock()
         self._load(state_dict)
@@ -185,17 +185,18 @@ class T3Engine:
 
         Steps are pipelined one deep inside the library: a call launches the next step and reports the
         previous one, so the first call after admission may report nothing and a call that switches to a
-        synchronous mode (timing, logit taps) may report two steps' tokens, in order."""
+        synchronous mode (timing, logit taps) may report two steps' tokens, in order.
+
+        A request whose logits have no finite maximum (non-finite weights or conditioning) is ended by the library and
+        reported once with finish reason "error" (its token is meaningless); the other requests of the step are
+        reported as usual, so a serving loop loses nothing of theirs.  ``generate`` raises for such a request after
+        the rest of its call has finished."""
         cap = 2 * self.max_num_seqs
         if getattr(self, "_step_bufs", None) is None:
             self._step_bufs = ((C.c_int64 * cap)(), (C.c_int32 * cap)(), (C.c_int32 * cap)(), C.c_int32(0))
         rid, tok, fin, n = self._step_bufs
         _capi.check(self._lib, self._lib.t3_engine_step(self._h, rid, tok, fin, cap, C.byref(n)))
-        out = [(rid[i], tok[i], _FINISH.get(fin[i])) for i in range(n.value)]
-        bad = [r for r, _, f in out if f == "error"]
-        if bad:                                 # the library has already ended those requests
-            raise _capi.T3Error(f"request(s) {bad}: logits without a finite maximum (non-finite weights or conditioning)")
-        return out
+        return [(rid[i], tok[i], _FINISH.get(fin[i])) for i in range(n.value)]
 
     def has_unfinished(self) -> bool:
         return bool(self._lib.t3_engine_has_unfinished(self._h))
@@ -209,10 +210,12 @@ class T3Engine:
         return s
 
     def set_schedule_policy(self, policy: str) -> None:
-        """Admission order for requests added from now on: 'fcfs' (vLLM's) or 'longest_first'."""
-        if policy not in ("fcfs", "longest_first"):
-            raise ValueError("scheduling_policy must be 'fcfs' (vLLM's default) or 'longest_first'")
-        _capi.check(self._lib, self._lib.t3_engine_set_schedule_policy(self._h, int(policy == "longest_first")))
+        """Admission order for requests added from now on: 'fcfs' (vLLM's), 'longest_prompt_first' (waiting requests
+        ranked by prompt length alone) or 'longest_first' (ranked by prompt length + max_tokens: a ranking by true
+        length only for a caller that sets max_tokens per request to the length it expects)."""
+        if policy not in SCHEDULING_POLICIES:
+            raise ValueError("scheduling_policy must be one of " + ", ".join(repr(p) for p in SCHEDULING_POLICIES))
+        _capi.check(self._lib, self._lib.t3_engine_set_schedule_policy(self._h, SCHEDULING_POLICIES.index(policy)))
         self.scheduling_policy = policy
 
     def set_timing(self, on: bool) -> None:
@@ -288,7 +291,8 @@ class T3Engine:
                     ro = by_id.get(rid)
                     if ro is None:
                         continue
-                    ro.outputs[0].token_ids.append(tok)
+                    if fin != "error":
+                        ro.outputs[0].token_ids.append(tok)
                     if fin is not None:
                         ro.outputs[0].finish_reason = fin
                         ro.finished = True
@@ -309,6 +313,13 @@ class T3Engine:
             except Exception:
                 pass
             raise
+        bad = [ro.request_id for ro in outs if ro.outputs[0].finish_reason == "error"]
+        if bad:
+            # every other request of the call ran to its end; the error carries all outputs (the failed ones with the
+            # tokens they had and finish_reason "error") for a caller that wants the healthy ones
+            err = _capi.T3Error(f"request(s) {bad}: logits without a finite maximum (non-finite weights or conditioning)")
+            err.outputs = outs
+            raise err
         return outs
 
     # ---- life cycle -------------------------------------------------------------------

@@ -81,6 +81,8 @@ class ChatterboxMultilingualTTS(ChatterboxTTS):
             items.append(it)
         # the sampling clamp applies when any language id is given (mtl_tts.py:453-459); the waveforms get the alignment cap
         # and tail trim (mtl_tts.py:592-644) in render_waveforms
+        # (per_prompt_clamp: each prompt clamped by its own language id, as separate calls would do: the streaming server)
         tokens_only = kwargs.pop("tokens_only", False)
-        toks = self._speech_tokens(items, any(langs), temperature, top_p, max_tokens, repetition_penalty, *args, **kwargs)
+        clamp = [bool(l) for l in langs] if kwargs.pop("per_prompt_clamp", False) else any(langs)
+        toks = self._speech_tokens(items, clamp, temperature, top_p, max_tokens, repetition_penalty, *args, **kwargs)
         return toks if self.s3gen is None or tokens_only else self.render_waveforms(toks, s3gen_ref, diffusion_steps)

@@ -241,16 +241,19 @@ class SpeechService:
         if not chunks:
             return
         tts = self.tts
-        lang = self._language(text, language_id)
+        # the reference synthesises chunk after chunk through _synthesize_one (openai_tts_server.py:501-509), so its
+        # language fallback looks at each chunk's own text (:406-411): mixed-script input gets a language per chunk
+        langs = [self._language(c, language_id) for c in chunks]
         first_steps = diffusion_steps if first_chunk_diff_steps is None else max(1, int(first_chunk_diff_steps))
-        yield tail_ramp(self.synthesize(chunks[0], language_id=lang, temperature=temperature, exaggeration=exaggeration,
+        yield tail_ramp(self.synthesize(chunks[0], language_id=langs[0], temperature=temperature, exaggeration=exaggeration,
                                         diffusion_steps=first_steps, audio_prompt_path=audio_prompt_path), self.sr)
         rest = chunks[1:]
         if not rest:
             return
         with self._lock:
             ref, cond = tts.get_audio_conditionals(audio_prompt_path)
-            toks = tts.generate_with_conds(prompts=rest, s3gen_ref=ref, cond_emb=cond, language_id=lang,
+            per_chunk = dict(language_id=langs[1:], per_prompt_clamp=True) if self._multilingual() else dict(language_id=language_id)
+            toks = tts.generate_with_conds(prompts=rest, s3gen_ref=ref, cond_emb=cond, **per_chunk,
                                            temperature=temperature, exaggeration=exaggeration,
                                            max_tokens=tts.max_model_len, **self._facade_defaults(),
                                            per_prompt_max_tokens=True, tokens_only=True)   # rendering follows per chunk

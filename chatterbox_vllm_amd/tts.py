@@ -62,36 +62,48 @@ def postprocess_speech_ids(token_ids: Sequence[int], prompt: str = "", tail_crop
     return torch.tensor(ids, dtype=torch.int64)
 
 
+def _env_ms(name: str, default: str, sr: int) -> int:
+    """An environment variable holding whole milliseconds, as samples at `sr`."""
+    return int(sr * int(os.environ.get(name, default)) / 1000)
+
+
+def _token_duration_cap(n_samples: int, n_tokens: int, sr: int) -> int:
+    """Samples to keep under the alignment rule: 25 speech tokens per second, plus CHATTERBOX_ALIGN_SAFETY_MS."""
+    return min(n_samples, int(round(n_tokens * (sr / 25))) + max(0, _env_ms("CHATTERBOX_ALIGN_SAFETY_MS", "0", sr)))
+
+
+def _quiet_tail_cut(wav: torch.Tensor, sr: int) -> int:
+    """Samples to keep under the tail rule: windowed RMS (CHATTERBOX_RMS_WINDOW_MS long, every CHATTERBOX_RMS_HOP_MS);
+    the last window louder than the threshold ends the utterance, CHATTERBOX_TAIL_TRIM_SAFETY_MS later.  The threshold
+    is CHATTERBOX_TAIL_TRIM_DB_REL below the loudest window, or the absolute CHATTERBOX_TAIL_TRIM_DB for pure silence."""
+    n = wav.shape[1]
+    window, hop = max(1, _env_ms("CHATTERBOX_RMS_WINDOW_MS", "50", sr)), max(1, _env_ms("CHATTERBOX_RMS_HOP_MS", "20", sr))
+    if n < window:
+        return n
+    # mean square per window as a strided convolution with a box filter: the reference's own arithmetic, so a window on
+    # the threshold falls on the same side
+    box = torch.full((1, 1, window), 1.0 / window, device=wav.device, dtype=wav.dtype)
+    level = torch.nn.functional.conv1d(wav.square().reshape(1, 1, -1), box, stride=hop).flatten().sqrt()
+    loudest = float(level.max()) if level.numel() else 0.0
+    db = float(os.environ.get("CHATTERBOX_TAIL_TRIM_DB_REL", "-35")) if loudest > 0 else float(os.environ.get("CHATTERBOX_TAIL_TRIM_DB", "-42"))
+    floor = (loudest if loudest > 0 else 1.0) * 10.0 ** (db / 20.0)
+    audible = (level > floor).nonzero()
+    if audible.numel() == 0:
+        return n
+    return min(n, (int(audible[-1]) + 1) * hop + _env_ms("CHATTERBOX_TAIL_TRIM_SAFETY_MS", "50", sr))
+
+
 def postprocess_waveform(wav: torch.Tensor, n_tokens: int, sr: int = S3GEN_SR) -> torch.Tensor:
     """What the reference does to a rendered waveform [1, N] before returning it (tts.py:495-541), same environment switches:
-    cut to the duration the speech tokens stand for (25 tokens per second, CHATTERBOX_ALIGN_HARD / _ALIGN_SAFETY_MS), then cut
-    the tail after the last 50 ms window (20 ms hop) whose RMS is within 35 dB of the loudest one, plus 50 ms
-    (CHATTERBOX_TAIL_TRIM, _TAIL_TRIM_DB, _TAIL_TRIM_DB_REL, _TAIL_TRIM_SAFETY_MS, _RMS_WINDOW_MS, _RMS_HOP_MS).  The optional
-    VAD trim behind CHATTERBOX_VAD_TRIM (tts.py:543-555) needs torchaudio and is not reproduced."""
-    on = lambda name, default: os.environ.get(name, default).lower() in ("1", "true", "yes", "on")
+    cut to the duration the speech tokens stand for (CHATTERBOX_ALIGN_HARD), then cut the quiet tail
+    (CHATTERBOX_TAIL_TRIM).  The optional VAD trim behind CHATTERBOX_VAD_TRIM (tts.py:543-555) needs torchaudio and is not
+    reproduced."""
     if wav is None or wav.numel() == 0:
         return wav
-    if on("CHATTERBOX_ALIGN_HARD", "1"):
-        expected = int(round(n_tokens * (sr / 25)))
-        safety = max(0, int(sr * int(os.environ.get("CHATTERBOX_ALIGN_SAFETY_MS", "0")) / 1000))
-        wav = wav[:, : min(wav.shape[1], expected + safety)]
-    if on("CHATTERBOX_TAIL_TRIM", "1") and wav.numel() > 0:
-        frame_len = max(1, int(sr * int(os.environ.get("CHATTERBOX_RMS_WINDOW_MS", "50")) / 1000))
-        hop_len = max(1, int(sr * int(os.environ.get("CHATTERBOX_RMS_HOP_MS", "20")) / 1000))
-        if wav.shape[1] >= frame_len:
-            x2 = (wav.unsqueeze(0) ** 2).view(1, 1, -1)
-            kernel = torch.ones(1, 1, frame_len, device=wav.device, dtype=wav.dtype) / frame_len
-            rms = torch.sqrt(torch.nn.functional.conv1d(x2, kernel, stride=hop_len)).reshape(-1)
-            peak = float(rms.max().item()) if rms.numel() > 0 else 0.0
-            if peak > 0:
-                thr = peak * (10.0 ** (float(os.environ.get("CHATTERBOX_TAIL_TRIM_DB_REL", "-35")) / 20.0))
-            else:
-                thr = 10.0 ** (float(os.environ.get("CHATTERBOX_TAIL_TRIM_DB", "-42")) / 20.0)
-            active = torch.where(rms > thr)[0]
-            if active.numel() > 0:
-                safety = int(sr * int(os.environ.get("CHATTERBOX_TAIL_TRIM_SAFETY_MS", "50")) / 1000)
-                cut = min(wav.shape[1], (int(active[-1].item()) + 1) * hop_len + safety)
-                wav = wav[:, :cut]
+    if _env_flag("CHATTERBOX_ALIGN_HARD", "1"):
+        wav = wav[:, : _token_duration_cap(wav.shape[1], n_tokens, sr)]
+    if _env_flag("CHATTERBOX_TAIL_TRIM", "1") and wav.numel() > 0:
+        wav = wav[:, : _quiet_tail_cut(wav, sr)]
     return wav
 
 
@@ -168,7 +180,7 @@ class ChatterboxTTS:
             s3_sd = load_file(str(ckpt_dir / "s3gen.safetensors"))
             kwargs["s3gen"] = S3Token2Wav({k[len("flow."):]: v for k, v in s3_sd.items() if k.startswith("flow.")},
                                           {k[len("mel2wav."):]: v for k, v in s3_sd.items() if k.startswith("mel2wav.")},
-                                          max_batch=min(8, max(1, max_batch_size)))
+                                          max_batch=min(4, max(1, max_batch_size)), chains=2)
         cfg = cls.variant_config(variant)
         # the backbone's depth is the checkpoint's (30 for the published ones): a cut-down checkpoint loads as what it is
         depth = 1 + max((int(k.split(".")[2]) for k in sd if k.startswith("tfmr.layers.")), default=-1)
@@ -207,7 +219,7 @@ class ChatterboxTTS:
             flow_sd = dict(flow_weights.synthetic_state_dict())
             flow_sd.update(cfm_weights.synthetic_state_dict())
             kwargs["s3gen"] = S3Token2Wav(flow_sd, hift_weights.synthetic_state_dict(), max_tokens=kwargs.get("max_model_len", 1000) + 256,
-                                          max_batch=min(8, max(1, kwargs.get("max_batch_size", 10))))
+                                          max_batch=min(4, max(1, kwargs.get("max_batch_size", 10))), chains=2)
         cfg = cls.variant_config(variant)
         if n_layers is not None:
             cfg = T3ModelConfig(n_layers=n_layers, text_vocab=cfg.text_vocab)
@@ -308,20 +320,26 @@ class ChatterboxTTS:
         ``per_prompt_max_tokens`` has no counterpart in the reference, whose calls share one ``max_tokens`` (the smallest
         prompt's, tts.py:378-393): with it every prompt gets the cap it would get in a call of its own, which is what lets
         the streaming server take the chunks of a request through one batched call and still return what chunk-by-chunk
-        calls return."""
-        temp_use, top_p_use = temperature, top_p
-        if clamp:                                                      # tts.py:350-356
-            temp_use, top_p_use = min(temperature, 0.5), min(top_p, 0.5)
-        if _env_flag("CHATTERBOX_DETERMINISTIC"):                      # tts.py:358-362
-            temp_use, top_p_use = 0.0, 1.0
+        calls return.  ``clamp`` (the reference's temperature / top_p clamp when a language id is given) may be a list
+        with one entry per prompt, for the same reason: chunks of one request may resolve to different languages."""
         prompts = [it["prompt"] for it in items]
+        clamps = [bool(c) for c in clamp] if isinstance(clamp, (list, tuple)) else [bool(clamp)] * len(prompts)
+
         # NOTE the reference forwards min_p only when the caller passes it through **kwargs (tts.py:410-417):
         # the named `min_p` parameter is accepted and not used.
-        def params(group):
+        def params(group, clamped):
+            temp_use, top_p_use = temperature, top_p
+            if clamped:                                                # tts.py:350-356
+                temp_use, top_p_use = min(temperature, 0.5), min(top_p, 0.5)
+            if _env_flag("CHATTERBOX_DETERMINISTIC"):                  # tts.py:358-362
+                temp_use, top_p_use = 0.0, 1.0
             return SamplingParams(temperature=temp_use, stop_token_ids=[STOP_OFFSET_ID],
                                   max_tokens=batch_max_tokens(group, max_tokens, self.max_model_len), top_p=top_p_use,
                                   repetition_penalty=repetition_penalty, *args, **kwargs)
-        sps = [params([p]) for p in prompts] if per_prompt_max_tokens else params(prompts)
+        if per_prompt_max_tokens or len(set(clamps)) > 1:
+            sps = [params([p] if per_prompt_max_tokens else prompts, c) for p, c in zip(prompts, clamps)]
+        else:
+            sps = params(prompts, bool(clamps) and clamps[0])
         t0 = time.time()
         outs = self.t3.generate(items, sampling_params=sps)
         self.last_t3_seconds = time.time() - t0
@@ -333,16 +351,12 @@ class ChatterboxTTS:
         """Speech tokens -> waveforms [1, N] on the CPU through the attached token -> waveform object, each with the
         reference's alignment cap and RMS tail trim (tts.py:489-541)."""
         results: List[Any] = [None] * len(all_toks)
-        per_call = getattr(self.s3gen, "max_batch", 1)
-        if per_call > 1 and hasattr(self.s3gen, "inference_batch"):
-            # the reference takes the utterances through S3Gen one after the other (tts.py:489-493); here those of similar
-            # length share the flow-matching stage's launches
-            order = sorted((i for i, t in enumerate(all_toks) if t.numel() > 0), key=lambda i: -all_toks[i].numel())
-            for j in range(0, len(order), per_call):
-                group = order[j:j + per_call]
-                wavs = self.s3gen.inference_batch([all_toks[i].to(self.target_device) for i in group], s3gen_ref,
-                                                  n_timesteps=diffusion_steps)
-                for i, wav in zip(group, wavs):
+        if hasattr(self.s3gen, "render_many"):
+            # the reference takes the utterances through S3Gen one after the other (tts.py:489-493); this package's chain
+            # takes those of similar length through the flow-matching stage together and keeps two copies of itself busy
+            wavs = self.s3gen.render_many([t.to(self.target_device) for t in all_toks], s3gen_ref, n_timesteps=diffusion_steps)
+            for i, wav in enumerate(wavs):
+                if wav is not None:
                     results[i] = postprocess_waveform(wav, int(all_toks[i].numel()), self.sr).cpu()
         for i, toks in enumerate(all_toks):
             if results[i] is None:

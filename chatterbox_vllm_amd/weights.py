@@ -59,44 +59,127 @@ def synthetic_state_dict(cfg: T3ModelConfig, seed: int = 1234) -> Dict[str, torc
     return sd
 
 
-DECISIVE_ACTIVE = 96          # speech ids that carry the structure of ``decisive_state_dict``
+DECISIVE_CODES = 256          # width of one code slice = number of orthogonal token codes
+DECISIVE_ACTIVE = 208         # speech ids that carry the structure of ``decisive_state_dict``
+DECISIVE_TEXT_CLASSES = 47    # text id t carries the code of class t % 47
+DECISIVE_TAG = 768            # residual coordinate that holds the same large value in every structured row
+DECISIVE_QK = 3.5             # q and k weight on the tag coordinate: peak score (3.97 * 3.5)^2 * 8 / 8 = 193
+DECISIVE_GROUPS = ((5, 1, 1.0), (37, 2, 1.0))                      # (look-back distance, slice written, amplitude)
+# head weights of the edges: first (strong, weak source), near, far (speech source, text source); 1 is a logit of 18.3
+DECISIVE_LEVELS = (1.57, 0.71, 1.05, 0.85, 0.85)
+DECISIVE_GROUPS_LONG = DECISIVE_GROUPS + ((150, 2, 0.8), (400, 2, 0.65))
 
 
-def decisive_state_dict(cfg: T3ModelConfig, seed: int = 1234, n_active: int = DECISIVE_ACTIVE, emb_scale: float = 4.0,
-                        gamma: float = 0.9, second: float = 0.75) -> Dict[str, torch.Tensor]:
-    """A seeded checkpoint whose greedy choice is decisive at every decode step, for tests that require token ids to
-    be EQUAL between two implementations that round alike but sum in different orders.
+def _sylvester(n: int) -> torch.Tensor:
+    """+-1 Hadamard matrix of order n (a power of two): rows are exactly orthogonal and exact in bf16."""
+    h = torch.ones(1, 1)
+    while h.shape[0] < n:
+        h = torch.cat([torch.cat([h, h], 1), torch.cat([h, -h], 1)], 0)
+    return h
 
-    ``synthetic_state_dict`` gives nearly flat logits: 8194 Gaussian values whose top-2 gap is a few bf16 ulp, so two
-    correct implementations may legitimately pick different ids.  Here ``n_active`` speech ids get embeddings large
-    enough to dominate the residual stream, and the speech head maps the direction of an active id ``a`` onto two
-    successors: ``first(a)`` with weight ``gamma`` and ``alt(a)`` with ``second * gamma``.  After token ``a`` the
-    logit of ``first(a)`` stands out (about 24, ``alt(a)`` 18, against a background of standard deviation 0.7); once
-    ``first(a)`` has been emitted the repetition penalty 2.0 halves it and ``alt(a)`` wins (18 against 12; with both
-    emitted 12 against 9), so the walk depends on the request's history
-    and, for multilingual prompts, on which text ids collide with speech columns.  Half of the active ids lie below
-    1454 (the columns multilingual text ids can reach).  A few ids lead to the stop id, so some walks end on "stop".
-    The FIRST token of a request is not structured: it comes from the start-of-speech row and depends on the
-    whole prompt, as with the flat checkpoint; tests pick prompts whose first step happens to be decisive.
-    Everything else (backbone, text tables, position tables) is ``synthetic_state_dict``'s."""
+
+def decisive_state_dict(cfg: T3ModelConfig, seed: int = 1234, groups=DECISIVE_GROUPS) -> Dict[str, torch.Tensor]:
+    """A seeded checkpoint whose greedy walk is decisive at (nearly) every step AND is decided by attention over the
+    paged history, the rotary positions, the text rows and the cond/uncond pairing, for tests that require token ids
+    to be EQUAL between two implementations that round alike but sum in different orders.
+
+    ``synthetic_state_dict`` gives nearly flat logits (top-2 gaps of a few bf16 ulp), so two correct implementations
+    may pick different ids.  Here the embeddings, the attention weights of layer 0 and the speech head are structured;
+    every other tensor (the MLP of layer 0, layers 1.., position tables, norms) is ``synthetic_state_dict``'s.
+
+    * Codes.  256 exactly orthogonal +-1 codes of 256 entries.  Code i < 208 belongs to active speech id ``act[i]``
+      (half of them below 1454, the columns multilingual text ids can reach), codes 208..254 to the 47 classes of
+      text ids (class = id % 47), code 255 to the start-of-speech id.  A structured embedding row is
+      ``[16 * code | 0 | 0 | 32 at coordinate 768, 0 ...]``: coordinates 0..255 identify the token, coordinate 768 is a
+      tag whose normalised value (3.97) is the same in every structured row.
+    * Layer 0 attention looks back a fixed distance.  Head group g (4 heads) has q = k = a constant taken from the tag
+      coordinate in the 8 fastest rotary pairs, with the key pre-rotated by ``delta_g`` positions, so after RoPE the
+      score is ``sum_j 12.3 cos((p - s - delta_g) theta_j)``: 98 at the row ``delta_g`` back, 88 next to it, below 75
+      elsewhere.  v copies the code coordinates, o writes them (scaled) into residual slice 1 (``delta = 5``) or slice
+      2 (``delta = 37``; ``DECISIVE_GROUPS_LONG`` adds 150 and 400 for long contexts).  Rows that are not structured
+      (the 34 conditioning rows: random tag; the zeroed text rows of the uncond stream: no key at all) are poor keys,
+      so a look-back that lands on them settles on another row.  Everything here is exact in bf16 or taken from one
+      coordinate, so two implementations form bit-identical scores.
+    * Speech head.  The row of ``first(a)`` holds a's code in slice 0, the rows of ``near(b)`` / ``far(b)`` hold b's
+      code in slice 1 / 2, with strengths that depend on the source token (strong / weak ``first``, loud / quiet
+      ``near`` and ``far``).  After token a at position p the candidates are first(a) (from the residual, no attention
+      needed), near(token at p-5) and far(token at p-37) (carried by attention, from the KV pages), at distinct logit
+      levels between 9 and 33; which one wins depends on the three source tokens and on what the repetition penalty has
+      already halved.
+    * Stream modes.  With CFG the logit is c + s (c - u).  When the uncond stream attends over its own KV, u carries
+      the same near / far votes as c unless the row looked at is a text row (zero in the uncond stream), whose vote is
+      then amplified by 1 + s.  When the uncond row has no attention, u carries no vote at all: every attention-borne
+      vote is amplified and the ``first`` vote is reduced.  With CFG off nothing is amplified.  The three modes
+      therefore walk differently from the first steps on, and a K/V page that is lost, misplaced or read at a wrong
+      position changes the ids.
+    A few ``first`` edges lead to the stop id, so some walks end on "stop"."""
     sd = synthetic_state_dict(cfg, seed)
+    d, S, n_act, n_cls, tag = cfg.d_model, DECISIVE_CODES, DECISIVE_ACTIVE, DECISIVE_TEXT_CLASSES, DECISIVE_TAG
+    assert d == 4 * S and cfg.n_heads * cfg.head_dim == d and n_act + n_cls + 1 == S and cfg.n_layers >= 1
     g = torch.Generator(device="cpu")
     g.manual_seed(seed + 77)
-    low = torch.randperm(1454, generator=g)[: n_active // 2]
-    high = 1454 + torch.randperm(6561 - 1454, generator=g)[: n_active - n_active // 2]
-    act = torch.cat([low, high])
-    emb = sd["speech_emb.weight"].to(torch.float32)
-    emb[act] = torch.randn(n_active, cfg.d_model, generator=g) * emb_scale
-    first = act[torch.randint(0, n_active, (n_active,), generator=g)]
-    alt = act[torch.randint(0, n_active, (n_active,), generator=g)]
-    stop_id = 6562                                        # modules/t3_config.py:9 (stop_speech_token)
-    first[torch.randperm(n_active, generator=g)[:3]] = stop_id
+    codes = _sylvester(S)
+    low = torch.randperm(1454, generator=g)[: n_act // 2]
+    high = 1454 + torch.randperm(6561 - 1454, generator=g)[: n_act - n_act // 2]
+    act = torch.cat([low, high])[torch.randperm(n_act, generator=g)]
+    sos_id, stop_id = 6561, 6562                         # modules/t3_config.py:8-9
+
+    def structured_row(code: int) -> torch.Tensor:
+        r = torch.zeros(d)
+        r[:S] = 16.0 * codes[code]
+        r[tag] = 32.0
+        return r
+
+    semb = sd["speech_emb.weight"].to(torch.float32)
+    for i in range(n_act):
+        semb[act[i]] = structured_row(i)
+    semb[sos_id] = structured_row(S - 1)
+    temb = sd["text_emb.weight"].to(torch.float32)
+    for t in range(cfg.text_vocab):
+        temb[t] = structured_row(n_act + t % n_cls)
+    sd["speech_emb.weight"] = semb.to(torch.bfloat16)
+    sd["text_emb.weight"] = temb.to(torch.bfloat16)
+
+    # layer 0: fixed look-back attention
+    inv = llama3_inv_freq(cfg)
+    wq, wk, wv, wo = (torch.zeros(d, d) for _ in range(4))
+    assert len(groups) <= cfg.n_heads // 4
+    for gi, (delta, slc, amp) in enumerate(groups):
+        for h in range(4 * gi, 4 * gi + 4):
+            for j in range(8):
+                phi = delta * float(inv[j])
+                wq[h * 64 + j, tag] = DECISIVE_QK
+                wk[h * 64 + j, tag] = DECISIVE_QK * math.cos(phi)
+                wk[h * 64 + 32 + j, tag] = DECISIVE_QK * math.sin(phi)
+        for i in range(S):
+            wv[S * gi + i, i] = 2.0
+            wo[S * slc + i, S * gi + i] = 4.0 * amp
+    p = "tfmr.layers.0.self_attn."
+    for name, w in (("q", wq), ("k", wk), ("v", wv), ("o", wo)):
+        sd[p + name + "_proj.weight"] = w.to(torch.bfloat16)
+
+    # speech head: first / near / far edges
     head = sd["speech_head.weight"].to(torch.float32)
-    unit = emb[act] / (emb_scale * math.sqrt(cfg.d_model))
-    for i in range(n_active):
-        head[first[i]] += gamma * unit[i]
-        head[alt[i]] += second * gamma * unit[i]
-    sd["speech_emb.weight"] = emb.to(torch.bfloat16)
+    head[act] *= 0.25
+
+    def cycle() -> torch.Tensor:
+        order = torch.randperm(n_act, generator=g)
+        nxt = torch.empty(n_act, dtype=torch.long)
+        nxt[order] = order.roll(-1)
+        return nxt
+
+    edges = []
+    for _ in range(3):                                   # one cycle over the active ids + targets for the 48 other codes
+        edges.append(act[torch.cat([cycle(), torch.randint(0, n_act, (S - n_act,), generator=g)])])
+    first, near, far = edges
+    first[torch.randperm(n_act, generator=g)[:3]] = stop_id
+    jitter = 1.0 + 0.03 * (2.0 * torch.rand(3, S, generator=g) - 1.0)      # no two edges of one kind weigh the same
+    f_strong, f_weak, w_near, w_far, w_far_text = DECISIVE_LEVELS
+    for i in range(S):
+        u = codes[i] / 16.0                               # unit norm
+        head[first[i], 0:S] += (f_strong if i % 2 == 0 else f_weak) * jitter[0, i] * u
+        head[near[i], S:2 * S] += w_near * jitter[1, i] * u
+        head[far[i], 2 * S:3 * S] += (w_far if i < n_act or i == S - 1 else w_far_text) * jitter[2, i] * u
     sd["speech_head.weight"] = head.to(torch.bfloat16)
     return sd
 

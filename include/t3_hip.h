@@ -125,9 +125,10 @@ int t3_engine_add_request(t3_engine* e, int64_t req_id, const int32_t* text_ids,
 int t3_engine_step(t3_engine* e, int64_t* out_req_ids, int32_t* out_tokens, int32_t* out_finished,
                    int32_t cap, int32_t* n_out);
 /* Admission order of waiting requests: 0 = first come first served (vLLM's default policy, what the reference
- * runs under, tts.py:130-140); 1 = longest first by prompt + max_tokens, which shortens the half-empty tail of a
- * queue that is known up front (one generate() call).  Applies to requests added afterwards; a request's tokens
- * do not depend on what it shares a step with. */
+ * runs under, tts.py:130-140); 2 = longest prompt first, which shortens the half-empty tail of a queue that is known
+ * up front (one generate() call) using only what every caller knows; 1 = longest first by prompt + max_tokens, the same
+ * idea for a caller that sets max_tokens per request to the length it expects.  Applies to requests added afterwards;
+ * a request's tokens do not depend on what it shares a step with. */
 int t3_engine_set_schedule_policy(t3_engine* e, int32_t policy);
 int t3_engine_abort(t3_engine* e, int64_t req_id);
 int t3_engine_has_unfinished(t3_engine* e);
@@ -191,6 +192,10 @@ int t3_op_gemm(const void* a_dev, const void* wt_dev, void* out_dev, int32_t M, 
  * t3_op_slab_split() ranges, slab[s][M][N] (fp32) receives the partial sums of range s. */
 int t3_op_gemm_slab(const void* a_dev, const void* wt_dev, float* slab_dev, int32_t M, int32_t N, int32_t K, void* stream);
 int t3_op_slab_split(void);
+/* Measurement / test switch, process-wide, no counterpart in the reference: which kernel prompt-row projections use from
+ * now on.  0 (default): one workgroup per 128-row tile; 1: one workgroup walks all rows of its weight tile, so every weight
+ * byte is fetched once per launch (slower below a few thousand rows).  Same bits either way. */
+int t3_op_set_prompt_gemm_form(int32_t walk);
 /* res = bf16(bf16(slab[0] + ... + slab[nsplit-1]) + res) (skipped when nsplit == 0), then
  * xn = rmsnorm(res) * w; d must be 1024; nsplit 0 or t3_op_slab_split().  The decode-path partner of t3_op_gemm_slab. */
 int t3_op_slab_add_rmsnorm(const float* slab_dev, int32_t nsplit, void* res_dev, const void* w_dev, void* xn_dev,

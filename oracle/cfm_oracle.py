@@ -1,17 +1,21 @@
 """CPU restatement of S3Gen's flow-matching decoder (mu -> mel).  TEST INFRASTRUCTURE ONLY: imported by tests/, by
 __graft_entry__.smoke() and by the CPU-baseline leg of the benchmarks, never by the package.
 
-PARITY UNPINNED.  The reference's modules for this stage cannot be imported here: matcha/decoder.py:7-8 and
-matcha/transformer.py:5-14 import `conformer` and `diffusers`, neither of which is installed, and the reference holds no
-output of this stage.  What follows restates the reference's own source where it has one and, for the three classes the
-reference takes from diffusers (`Attention`, `GELU`, `LoRACompatibleLinear`; the dependency is unpinned in
-pyproject.toml:25), the published algorithm with torch's own primitives:
-  Attention(query_dim=256, heads=8, dim_head=64, bias=False), self-attention, default processor:
-      q, k, v = to_q(x), to_k(x), to_v(x) (no bias) split into 8 heads of 64;
-      softmax(q k^T / sqrt(64) + mask) v; to_out[0] (Linear 512 -> 256 with bias); to_out[1] is dropout 0
-  GELU(256, 1024): Linear then F.gelu (erf form);  LoRACompatibleLinear without adapters: nn.Linear.
-Nothing here is checked against reference outputs; the tests hold the GPU path to this file, and this file to the
-structural properties the algorithm has (causality of the convolutions, the guidance algebra, the time grid).
+PARITY: pinned to outputs of the reference's own code, except for the inside of three third-party classes.
+tests/golden/make_cfm_fixtures.py imports the reference's decoder.py, matcha/decoder.py, matcha/transformer.py and
+flow_matching.py unmodified (the absent packages `conformer`, `diffusers`, `omegaconf` are stand-in modules) and records
+their outputs on this repository's seeded weights -> tests/golden/cfm_fixture.npz; tests/test_cfm_oracle.py holds this file
+to them:
+  * SinusoidalPosEmb, TimestepEmbedding, CausalConv1d, CausalBlock1D, CausalResnetBlock1D, and solve_euler /
+    CausalConditionalCFM.forward around a closed-form estimator: the reference's own arithmetic alone;
+  * ConditionalDecoder.forward whole and the 10-step solve around it: the reference's own module tree and forward code
+    with the three classes it takes from diffusers (`Attention`, `GELU`, `LoRACompatibleLinear`; the dependency is
+    unpinned in pyproject.toml:25) replaced by labelled minimal stand-ins written from diffusers' published behaviour:
+      Attention(query_dim=256, heads=8, dim_head=64, bias=False), self-attention, default processor:
+          q, k, v = to_q(x), to_k(x), to_v(x) (no bias) split into 8 heads of 64;
+          softmax(q k^T / sqrt(64) + mask) v; to_out[0] (Linear 512 -> 256 with bias); to_out[1] is dropout 0
+      GELU(256, 1024): Linear then F.gelu (erf form);  LoRACompatibleLinear without adapters: nn.Linear.
+STILL UNPINNED: the inside of those three classes (diffusers is not installed; the reference holds no output of them).
 
 What it restates (reference files under /root/reference/src/chatterbox_vllm/models/s3gen/):
   ConditionalDecoder.forward, decoder.py:233-317 (one down stage, twelve mid stages, one up stage with the skip
@@ -116,11 +120,12 @@ def estimator(w, x, mu, t, spks, cond, taps=None):
     return F.conv1d(x, w[P + "final_proj.weight"], w[P + "final_proj.bias"])
 
 
-def solve_euler(w, z, t_span, mu, spks, cond, dtype=torch.float32, sol=None):
+def solve_euler(w, z, t_span, mu, spks, cond, dtype=torch.float32, sol=None, estimator_fn=None):
     """flow_matching.py:82-133 for one utterance: row 0 of every estimator call is conditioned, row 1 sees zeros for mu,
     spks and cond; the two velocity estimates are combined with the guidance rate 0.7.  t and dt advance in the
-    arithmetic of t_span (fp32 in the reference), whatever `dtype` the network runs in."""
-    w = {k: v.to(dtype) for k, v in w.items()}
+    arithmetic of t_span (fp32 in the reference), whatever `dtype` the network runs in.  `estimator_fn(x, mu, t, spks,
+    cond)` replaces the network (the fixture's closed-form estimator)."""
+    w = {k: v.to(dtype) for k, v in w.items()} if estimator_fn is None else None
     x = z.to(dtype)
     t, dt = t_span[0], t_span[1] - t_span[0]
     n = len(t_span)
@@ -130,7 +135,7 @@ def solve_euler(w, z, t_span, mu, spks, cond, dtype=torch.float32, sol=None):
         sp_in = torch.cat([spks.to(dtype), torch.zeros_like(spks, dtype=dtype)], dim=0)
         c_in = torch.cat([cond.to(dtype), torch.zeros_like(cond, dtype=dtype)], dim=0)
         t_in = torch.stack([t, t]).to(dtype)
-        d = estimator(w, x_in, mu_in, t_in, sp_in, c_in)
+        d = estimator(w, x_in, mu_in, t_in, sp_in, c_in) if estimator_fn is None else estimator_fn(x_in, mu_in, t_in, sp_in, c_in)
         d = (1.0 + CFG_RATE) * d[0:1] - CFG_RATE * d[1:2]
         x = x + dt.to(dtype) * d
         t = t + dt
@@ -141,10 +146,10 @@ def solve_euler(w, z, t_span, mu, spks, cond, dtype=torch.float32, sol=None):
     return x
 
 
-def cfm_forward(w, mu, spks, cond, noise, n_timesteps=10, temperature=1.0, dtype=torch.float32):
+def cfm_forward(w, mu, spks, cond, noise, n_timesteps=10, temperature=1.0, dtype=torch.float32, estimator_fn=None):
     """CausalConditionalCFM.forward, flow_matching.py:203-228; `noise` stands for the leading columns of the module's
     `rand_noise` buffer."""
     z = noise[:, :, :mu.shape[2]] * temperature
     t_span = torch.linspace(0, 1, n_timesteps + 1, dtype=torch.float32)
     t_span = 1 - torch.cos(t_span * 0.5 * torch.pi)
-    return solve_euler(w, z, t_span, mu, spks, cond, dtype)
+    return solve_euler(w, z, t_span, mu, spks, cond, dtype, estimator_fn=estimator_fn)

@@ -90,14 +90,26 @@ class _Stream:
     k: List[torch.Tensor] = field(default_factory=list)   # per layer [S,H,hd]
     v: List[torch.Tensor] = field(default_factory=list)
     attends: bool = True
+    # fault injection for the golden maker: (layer, first position, end position) whose K and V read as zero, the way
+    # a lost or never-written KV page would; None = no fault
+    lost_kv: Optional[Tuple[int, int, int]] = None
+
+    def apply_fault(self, li: int) -> None:
+        if self.lost_kv is not None and self.lost_kv[0] == li:
+            _, a, b = self.lost_kv
+            self.k[li][a:b] = 0
+            self.v[li][a:b] = 0
 
 
 class T3Oracle:
     def __init__(self, state_dict: Dict[str, torch.Tensor], n_layers: int = 30,
                  n_heads: int = 16, head_dim: int = 64, rms_eps: float = 1e-5,
                  cfg_scale: float = 0.5, bf16: bool = True, uncond_attends: bool = True,
-                 rope: Optional[torch.Tensor] = None, max_pos: int = 4096):
+                 rope: Optional[torch.Tensor] = None, max_pos: int = 4096, accumulate_fp64: bool = False):
         self.L, self.H, self.hd = n_layers, n_heads, head_dim
+        # accumulate_fp64: matrix products summed in double before the one rounding.  Same contract, other summation
+        # error: the golden maker uses it to reject cases whose ids hinge on the order of an fp32 sum.
+        self.accumulate_fp64 = accumulate_fp64
         self.eps = rms_eps
         self.cfg_scale = float(cfg_scale)
         self.bf16 = bf16
@@ -136,6 +148,12 @@ class T3Oracle:
     # ---- rounding helper ------------------------------------------------------
     def r(self, x: torch.Tensor) -> torch.Tensor:
         return x.to(torch.bfloat16).to(torch.float32) if self.bf16 else x
+
+    def mm(self, x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+        """x @ w.T, rounded once to the storage type."""
+        if self.accumulate_fp64:
+            return self.r((x.double() @ w.double().T).float())
+        return self.r(x @ w.T)
 
     # ---- embeddings -----------------------------------------------------------
     def prefill_embeds(self, text_ids: Sequence[int], cond_emb: torch.Tensor
@@ -179,7 +197,7 @@ class T3Oracle:
             else:
                 res = self.r(x + res)
             xn = self._rms(res, lw["ln1"])
-            qkv = self.r(xn @ lw["wqkv"].T)
+            qkv = self.mm(xn, lw["wqkv"])
             q, k, v = qkv.split(self.d, dim=-1)
             q = self._rope(q.view(T, self.H, self.hd), pos)
             k = self._rope(k.view(T, self.H, self.hd), pos)
@@ -189,6 +207,7 @@ class T3Oracle:
             else:
                 st.k[li] = torch.cat([st.k[li], k], 0)
                 st.v[li] = torch.cat([st.v[li], v], 0)
+            st.apply_fault(li)
             if st.attends:
                 K, V = st.k[li], st.v[li]
                 S = K.shape[0]
@@ -200,13 +219,13 @@ class T3Oracle:
                 a = self.r(torch.einsum("hts,shd->thd", p, V)).reshape(T, self.d)
             else:
                 a = torch.zeros(T, self.d)
-            x = self.r(a @ lw["wo"].T)
+            x = self.mm(a, lw["wo"])
             res = self.r(x + res)
             xn = self._rms(res, lw["ln2"])
-            gu = self.r(xn @ lw["wgu"].T)
+            gu = self.mm(xn, lw["wgu"])
             g, u = gu.split(self.ff, dim=-1)
             h = self.r(self.r(g / (1.0 + torch.exp(-g))) * u)
-            x = self.r(h @ lw["wd"].T)
+            x = self.mm(h, lw["wd"])
             if taps is not None and li in taps.get("layers", ()):
                 taps[f"layer{li}"] = self.r(x + res).clone()
         if res is None:
@@ -225,7 +244,7 @@ class T3Oracle:
         for li, lw in enumerate(self.layers):
             res = x if res is None else self.r(x + res)
             xn = self._rms(res, lw["ln1"])
-            qkv = self.r(xn @ lw["wqkv"].T)
+            qkv = self.mm(xn, lw["wqkv"])
             q, k, v = qkv.split(self.d, dim=-1)
             q = self._rope(q.view(R, self.H, self.hd), pos_t)
             k = self._rope(k.view(R, self.H, self.hd), pos_t)
@@ -234,18 +253,19 @@ class T3Oracle:
             for r_, st in enumerate(streams):
                 st.k[li] = torch.cat([st.k[li], k[r_:r_ + 1]], 0)
                 st.v[li] = torch.cat([st.v[li], v[r_:r_ + 1]], 0)
+                st.apply_fault(li)
                 if st.attends:
                     sc = torch.einsum("hd,shd->hs", q[r_], st.k[li]) * 0.125
                     rows.append(torch.einsum("hs,shd->hd", torch.softmax(sc, -1), st.v[li]).reshape(self.d))
                 else:
                     rows.append(torch.zeros(self.d))
             a = self.r(torch.stack(rows))
-            x = self.r(a @ lw["wo"].T)
+            x = self.mm(a, lw["wo"])
             res = self.r(x + res)
             xn = self._rms(res, lw["ln2"])
-            gu = self.r(xn @ lw["wgu"].T)
+            gu = self.mm(xn, lw["wgu"])
             g, u = gu.split(self.ff, dim=-1)
-            x = self.r(self.r(self.r(g / (1.0 + torch.exp(-g))) * u) @ lw["wd"].T)
+            x = self.mm(self.r(self.r(g / (1.0 + torch.exp(-g))) * u), lw["wd"])
         res = x if res is None else self.r(x + res)
         return self._rms(res, self.norm_w)
 
@@ -290,7 +310,7 @@ class T3Oracle:
 
     # ---- logits ---------------------------------------------------------------
     def head_logits(self, h: torch.Tensor) -> torch.Tensor:
-        return self.r(h @ self.head.T)
+        return self.mm(h, self.head)
 
     def cfg_logits(self, c: torch.Tensor, u: Optional[torch.Tensor]) -> torch.Tensor:
         """t3.py:732-738.  Returns [.., 9194]: 1000 -inf columns then the speech logits."""
@@ -334,17 +354,19 @@ class T3Oracle:
     def generate_one(self, text_ids: Sequence[int], cond_emb: torch.Tensor, spec: SamplingSpec,
                      max_model_len: int = 1000, paired: bool = True,
                      forced: Optional[Sequence[int]] = None, return_logits: bool = False,
-                     generator: Optional[torch.Generator] = None):
+                     generator: Optional[torch.Generator] = None,
+                     lost_kv: Optional[Tuple[int, int, int]] = None):
         """Greedy (or sampled) speech-token ids in the engine's +1000 id space, stop id
         included when emitted.  ``forced`` teacher-forces the given ids (still returns the
-        oracle's own choice per step in ``picks``)."""
+        oracle's own choice per step in ``picks``).  ``lost_kv`` = (layer, first, end): the cond
+        stream's K/V at those positions of that layer read as zero (fault injection, see _Stream)."""
         prompt = build_prompt_ids(text_ids)
         P = len(prompt)
         if P > max_model_len:
             raise ValueError(f"prompt of {P} tokens exceeds max_model_len={max_model_len}")
         ce, ue = self.prefill_embeds(text_ids, cond_emb)
         pos = torch.arange(P)
-        sc = _Stream()
+        sc = _Stream(lost_kv=lost_kv)
         su = _Stream(attends=self.uncond_attends)
         hc = self.forward(ce, pos, sc)[-1:]
         hu = self.forward(ue, pos, su)[-1:] if paired else None

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Writes tests/golden/oracle_golden.json: what the CPU oracle (oracle/t3_oracle.py) computes for small, seeded
-cases, so that (a) a change of the oracle's arithmetic shows up as a diff of committed data and (b) the GPU engine
-can be checked against data in the tree.
+"""Writes tests/golden/oracle_golden.json and tests/golden/long_context_golden.npz: what the CPU oracle
+(oracle/t3_oracle.py) computes for small, seeded cases, so that (a) a change of the oracle's arithmetic shows up as a
+diff of committed data and (b) the GPU engine can be checked against data in the tree.
 
-    python tests/golden/make_oracle_golden.py            (a few minutes on 8 cores)
+    python tests/golden/make_oracle_golden.py            (about half an hour on 8 cores)
 
 Flat cases (weights: chatterbox_vllm_amd.weights.synthetic_state_dict, seed 1234; cond: synthetic_cond_emb(voice)):
   micro  2 layers, two requests, 16 greedy tokens, CFG scale 0.5
@@ -11,19 +11,31 @@ Flat cases (weights: chatterbox_vllm_amd.weights.synthetic_state_dict, seed 1234
 Their logits are nearly flat (top-2 gaps of a few bf16 ulp), so they serve as LOGIT checks: ids are compared only on
 the steps that happen to be decisive.
 
-Decisive cases (weights: decisive_state_dict, seed 1234):
+Decisive cases (weights: decisive_state_dict, seed 1234: the winner of a step is picked by layer-0 attention over the
+paged history at fixed look-back distances, by the text rows and by the cond / uncond pairing):
   decisive_micro  2 layers,  >= 4 requests, up to 80 greedy tokens, CFG scale 0.5
   decisive_full   30 layers, >= 4 requests, up to 80 greedy tokens, CFG scale 0.5
-Requests are searched among seeded candidates (text length, voice) and kept only if EVERY step of EVERY stream mode
-has a top-2 margin above DECISIVE_FACTOR tolerances (tests/parity_bar.py), its first token differs from those of the
-requests already kept (so the walks differ) and the request yields at least 64 tokens;
-one more request that ends early on the stop id is kept when the search meets one.  This script refuses to write a
-decisive case with fewer than four such requests.  For these cases the tests require engine ids == golden ids for
-the whole sequence.
+Requests are searched among seeded candidates (text length, voice).  A candidate is kept only if
+  1. EVERY step of EVERY stream mode has a top-2 margin above DECISIVE_FACTOR tolerances (tests/parity_bar.py);
+  2. its three stream modes give pairwise DIFFERENT id sequences within the first 16 steps (so a wrong pairing mode,
+     a swapped cond / uncond row or an unattended uncond stream cannot reproduce the ids);
+  3. losing one KV page changes the ids: with the cond stream's K/V of positions 0..63, or of 64..127, of layer 0
+     reading as zero, the own-KV walk leaves the recorded one (both faults, each recorded with the step it shows at);
+  4. the ids of every mode are the same when the oracle sums its matrix products in double (so no id hinges on the
+     order of an fp32 sum);
+  5. it yields at least 64 tokens; one more request that ends early on the stop id is kept when the search meets one.
+This script refuses to write a decisive case with fewer than four such requests.  For these cases the tests require
+engine ids == golden ids for the whole sequence.
 
 Every case is run under the three semantics of the uncond stream (own KV / no attention / CFG off).  Per request
 and mode: the prompt ids, the greedy ids (+1000 space), the finish reason, per step the top-2 margin of the penalised
 logits, the top logit, the first 8 speech logits and (decisive cases) the larger head-row scale of the top-2 columns.
+
+long_context_golden.npz: 30 layers, decisive_state_dict with the long look-back groups (5, 37, 150 and 400 positions),
+one request whose 478 text ids make a prompt of 515 positions, 72 greedy tokens (positions 515..586), CFG-paired with
+own KV, scale 0.5.  Holds the text ids, the ids, per step margin / top logit / row scale, and the FULL row of 8194
+penalised speech logits at 10 steps; kept only if every step is decisive, ids survive double-precision summation,
+and zeroing any one of at least five different KV pages of layer 0 changes the ids.
 """
 import json
 import os
@@ -83,18 +95,24 @@ def all_decisive(r, tol, row_scale):
     return all(PB.step_is_decisive(row, tol, row_scale) for row in r["logits"])
 
 
+def first_difference(a, b):
+    return next((i for i, (x, y) in enumerate(zip(a, b)) if x != y), None if len(a) == len(b) else min(len(a), len(b)))
+
+
 def decisive_case(n_layers, want=4, max_candidates=400):
-    """Search seeded candidates for requests whose every step is decisive in every mode."""
+    """Search seeded candidates for requests that meet rules 1-5 of the module docstring."""
     cfg = T3ModelConfig.english(n_layers=n_layers)
     sd = W.decisive_state_dict(cfg)
     row_scale = PB.head_row_scale(sd)
     oracles = {mode: T3Oracle(sd, n_layers=n_layers, cfg_scale=CFG_SCALE if paired else 0.0, **kw)
                for mode, kw, paired in MODES}
+    doubles = {mode: T3Oracle(sd, n_layers=n_layers, cfg_scale=CFG_SCALE if paired else 0.0, accumulate_fp64=True, **kw)
+               for mode, kw, paired in MODES}
     tols = {mode: PB.logit_tol(CFG_SCALE if paired else 0.0, n_layers) for mode, _, paired in MODES}
     out = {"n_layers": n_layers, "cfg_scale": CFG_SCALE, "max_tokens": DEC_TOK, "max_model_len": 256,
            "checkpoint": "decisive_state_dict(seed=1234)", "decisive_factor": PB.DECISIVE_FACTOR, "requests": []}
     long_ones, short_stop, tried = 0, 0, 0
-    first_tokens = set()
+    rejected = {"not decisive": 0, "modes coincide": 0, "lost page unseen": 0, "summation order": 0, "length": 0}
     t0 = time.time()
     for cand in range(max_candidates):
         if long_ones >= want and (short_stop >= 1 or cand > 120):
@@ -103,57 +121,121 @@ def decisive_case(n_layers, want=4, max_candidates=400):
         v = cand % 3
         cond = W.synthetic_cond_emb(v)
         tried += 1
-        # stage 1: the first step (the only one that depends on the whole prompt) in every mode; requests whose walk
-        # starts where an accepted one started would only repeat it
-        ok = True
-        for mode, _, paired in MODES:
-            r = oracles[mode].generate_one(t, cond, SamplingSpec(max_tokens=1), max_model_len=256, paired=paired,
-                                           return_logits=True)
-            if not all_decisive(r, tols[mode], row_scale) or r["token_ids"][0] in first_tokens:
-                ok = False
-                break
-        if not ok:
-            continue
-        # stage 2: the whole sequence
         rec = {"text_ids": t, "voice": v, "prompt_ids": build_prompt_ids(t), "modes": {}}
-        for mode, _, paired in MODES:
+        ids, ok = {}, True
+        for mode, _, paired in MODES:                                       # rule 1
             r = oracles[mode].generate_one(t, cond, SamplingSpec(max_tokens=DEC_TOK), max_model_len=256, paired=paired,
                                            return_logits=True)
             if not all_decisive(r, tols[mode], row_scale):
                 ok = False
                 break
             rec["modes"][mode] = record(r, row_scale)
+            ids[mode] = r["token_ids"]
         if not ok:
+            rejected["not decisive"] += 1
             continue
-        lens = [len(m["token_ids"]) for m in rec["modes"].values()]
-        if min(lens) >= DEC_MIN and long_ones < want:
+        names = [m for m, _, _ in MODES]
+        diffs = {f"{a}|{b}": first_difference(ids[a], ids[b]) for i, a in enumerate(names) for b in names[i + 1:]}
+        if any(d is None or d >= 16 for d in diffs.values()):               # rule 2
+            rejected["modes coincide"] += 1
+            continue
+        lost = {}
+        for page in (0, 1):                                                 # rule 3
+            r = oracles["paired_own_kv"].generate_one(t, cond, SamplingSpec(max_tokens=DEC_TOK), max_model_len=256,
+                                                      lost_kv=(0, 64 * page, 64 * page + 64))
+            lost[f"layer0_page{page}"] = first_difference(r["token_ids"], ids["paired_own_kv"])
+        if any(d is None for d in lost.values()):
+            rejected["lost page unseen"] += 1
+            continue
+        same = all(doubles[mode].generate_one(t, cond, SamplingSpec(max_tokens=DEC_TOK), max_model_len=256,
+                                              paired=paired)["token_ids"] == ids[mode] for mode, _, paired in MODES)
+        if not same:                                                        # rule 4
+            rejected["summation order"] += 1
+            continue
+        lens = [len(x) for x in ids.values()]
+        if min(lens) >= DEC_MIN and long_ones < want:                       # rule 5
             long_ones += 1
-        elif max(lens) < DEC_MIN and min(lens) >= 4 and short_stop < 1:
+        elif min(lens) < DEC_MIN and min(lens) >= 4 and short_stop < 1:
             short_stop += 1                                  # ends on the stop id early: covers the stop rule
         else:
+            rejected["length"] += 1
             continue
+        rec["modes_first_differ_at"] = diffs
+        rec["lost_kv_page_shows_at"] = lost
         out["requests"].append(rec)
-        first_tokens.update(m["token_ids"][0] for m in rec["modes"].values())
-        print(f"  L={n_layers}: kept candidate {cand} (text {len(t)}, voice {v}), lengths {lens}, "
-              f"{time.time() - t0:.0f} s", flush=True)
+        print(f"  L={n_layers}: kept candidate {cand} (text {len(t)}, voice {v}), lengths {lens}, modes differ at "
+              f"{diffs}, lost pages show at {lost}, {time.time() - t0:.0f} s", flush=True)
     if long_ones < want:
         raise SystemExit(f"only {long_ones} decisive requests of >= {DEC_MIN} tokens among {tried} candidates at "
-                         f"{n_layers} layers: not writing a golden")
+                         f"{n_layers} layers ({rejected}): not writing a golden")
     out["candidates_tried"] = tried
+    out["candidates_rejected"] = rejected
     return out
 
 
+LONG_STEPS = (0, 1, 2, 9, 19, 29, 39, 49, 59, 70)
+
+
+def long_context_case(n_layers=30, n_text=478, n_tok=72, max_candidates=12):
+    """One request across position 512 on the long look-back checkpoint, with full logit rows."""
+    cfg = T3ModelConfig.english(n_layers=n_layers)
+    sd = W.decisive_state_dict(cfg, groups=W.DECISIVE_GROUPS_LONG)
+    row_scale = PB.head_row_scale(sd)
+    tol = PB.logit_tol(CFG_SCALE, n_layers)
+    o = T3Oracle(sd, n_layers=n_layers, cfg_scale=CFG_SCALE)
+    o64 = T3Oracle(sd, n_layers=n_layers, cfg_scale=CFG_SCALE, accumulate_fp64=True)
+    spec = SamplingSpec(max_tokens=n_tok)
+    for cand in range(max_candidates):
+        t, v = text(n_text - 2, 4242 + cand), cand % 3
+        cond = W.synthetic_cond_emb(v)
+        t0 = time.time()
+        r = o.generate_one(t, cond, spec, max_model_len=640, return_logits=True)
+        if len(r["token_ids"]) < n_tok or not all_decisive(r, tol, row_scale):
+            print(f"  long: candidate {cand} not decisive / too short ({len(r['token_ids'])} ids)", flush=True)
+            continue
+        if o64.generate_one(t, cond, spec, max_model_len=640)["token_ids"] != r["token_ids"]:
+            print(f"  long: candidate {cand} depends on the summation order", flush=True)
+            continue
+        lost = {}
+        for page in range(1, 9):
+            f = o.generate_one(t, cond, spec, max_model_len=640, lost_kv=(0, 64 * page, 64 * page + 64))
+            lost[page] = first_difference(f["token_ids"], r["token_ids"])
+        seen = [p for p, d in lost.items() if d is not None]
+        print(f"  long: candidate {cand}: lost pages show at {lost}, {time.time() - t0:.0f} s", flush=True)
+        if len(seen) < 5:
+            continue
+        L = r["logits"]
+        top2, idx = torch.topk(L, 2, dim=-1)
+        return dict(n_layers=n_layers, cfg_scale=CFG_SCALE, max_tokens=n_tok, max_model_len=640, voice=v,
+                    text_ids=torch.tensor(t, dtype=torch.int32).numpy(),
+                    token_ids=torch.tensor(r["token_ids"], dtype=torch.int32).numpy(),
+                    margins=(top2[:, 0] - top2[:, 1]).numpy(), top_logit=top2[:, 0].numpy(),
+                    top2_row_scale=torch.stack([row_scale[i].max() for i in idx]).numpy(),
+                    logit_steps=torch.tensor(LONG_STEPS, dtype=torch.int32).numpy(),
+                    logit_rows=torch.stack([L[s, 1000:] for s in LONG_STEPS]).numpy(),
+                    lost_page_shows_at=torch.tensor([-1 if lost[p] is None else lost[p] for p in range(1, 9)],
+                                                    dtype=torch.int32).numpy())
+    raise SystemExit("no long-context candidate met the rules: not writing a golden")
+
+
 def main():
+    import numpy as np
     torch.set_num_threads(8)
-    data = {"micro": case(2, [text(5, 11), text(40, 12)], [0, 1]),
-            "full": case(30, [text(7, 1), text(7, 2)], [0, 1]),
-            "decisive_micro": decisive_case(2),
-            "decisive_full": decisive_case(30)}
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle_golden.json")
-    with open(path, "w") as f:
-        json.dump(data, f, indent=0)
-        f.write("\n")
-    print("wrote", path, os.path.getsize(path), "bytes")
+    here = os.path.dirname(os.path.abspath(__file__))
+    if "--long-only" not in sys.argv:
+        data = {"micro": case(2, [text(5, 11), text(40, 12)], [0, 1]),
+                "full": case(30, [text(7, 1), text(7, 2)], [0, 1]),
+                "decisive_micro": decisive_case(2),
+                "decisive_full": decisive_case(30)}
+        path = os.path.join(here, "oracle_golden.json")
+        with open(path, "w") as f:
+            json.dump(data, f, indent=0)
+            f.write("\n")
+        print("wrote", path, os.path.getsize(path), "bytes", flush=True)
+    if "--json-only" not in sys.argv:
+        path = os.path.join(here, "long_context_golden.npz")
+        np.savez_compressed(path, **long_context_case())
+        print("wrote", path, os.path.getsize(path), "bytes", flush=True)
 
 
 if __name__ == "__main__":

@@ -39,6 +39,26 @@ def test_struct_layouts_match_header_sizes():
     assert C.sizeof(_capi.T3GemmDesc) == 5 * 8 + 10 * 4 + 4 * 8 + 8 + 8 + 2 * 4 + 4 * 8 + 4 + 4 + 8
 
 
+def test_integration_sketch_declares_the_structs_of_the_binding():
+    """INTEGRATION.md shows a maintainer the ctypes structures to declare.  The two struct declarations of that sketch
+    are executed here as written and must have the field names, types and sizes of the package's own binding, so the
+    document cannot drift from the ABI."""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n(.*?)```", doc, flags=re.S).group(1)
+    structs = re.findall(r"^class (T3Config|T3Sampling)\(C\.Structure\):\n((?:    .*\n|\n)+?)(?=^\S)", code, flags=re.M)
+    assert [n for n, _ in structs] == ["T3Config", "T3Sampling"]
+    ns = {"C": C}
+    for name, body in structs:
+        exec(f"class {name}(C.Structure):\n{body}", ns)
+    for name in ("T3Config", "T3Sampling"):
+        mine, theirs = getattr(_capi, name), ns[name]
+        assert C.sizeof(theirs) == C.sizeof(mine), name
+        assert [(f[0], f[1]) for f in theirs._fields_] == [(f[0], f[1]) for f in mine._fields_], name
+    # the sketch's positional T3Sampling(...) call fills every field
+    call = re.search(r"sp = T3Sampling\((.*?)\)\n", code, flags=re.S).group(1)
+    assert len([a for a in re.split(r",\s*(?![^()]*\))", call) if a.strip()]) == len(_capi.T3Sampling._fields_)
+
+
 def test_argument_errors_are_reported_not_crashed():
     lib = _capi.load()
     h = C.c_void_p()

@@ -1,9 +1,15 @@
 """GPU tests of the flow-matching decoder (include/s3cfm_hip.h) against oracle/cfm_oracle.py run in fp64 on the same seeded
-weights and inputs.  The oracle is PARITY UNPINNED (see its header): these tests show the HIP path computes what the
-restatement states, to fp32 rounding; they cannot show that the restatement equals the reference's diffusers-backed modules.
+weights and inputs, and against tests/golden/cfm_fixture.npz: outputs of the reference's own ConditionalDecoder.forward and
+CausalConditionalCFM.forward on those weights (made by tests/golden/make_cfm_fixtures.py; the three classes the reference
+takes from diffusers are labelled stand-ins there, so the inside of `Attention`, `GELU` and `LoRACompatibleLinear` is the one
+part these tests cannot pin).
 
 Tolerances are relative to the largest magnitude of the compared tensor: 2e-5 for one estimator call (about 70 layers of
-fp32 arithmetic against fp64), 1e-4 for the ten-step solve (the fp32 restatement itself sits 1e-5 from the fp64 one)."""
+fp32 arithmetic against fp64; 3e-5 against the reference's fp32 output, which carries its own rounding), 1e-4 for the
+ten-step solve (the fp32 restatement itself sits 1e-5 from the fp64 one)."""
+import os
+
+import numpy as np
 import pytest
 import torch
 
@@ -43,6 +49,30 @@ def test_estimator_matches_the_restatement(cfm, sd, L, t):
     tt = torch.tensor([t, t], dtype=torch.float32).double()
     want = O.estimator(w, x.double(), mu.double(), tt, spks.double(), cond.double())
     assert _rel(got, want) < 2e-5
+
+
+@pytest.fixture(scope="module")
+def fx():
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "cfm_fixture.npz"))
+    return {k: torch.from_numpy(z[k]) if z[k].ndim else z[k].item() for k in z.files}
+
+
+@pytest.mark.parametrize("tag", ["b1", "b2"])
+def test_estimator_matches_the_reference_module_tree(cfm, fx, tag):
+    """s3cfm_estimator against the reference's own ConditionalDecoder.forward (decoder.py:233-317) on the seeded weights."""
+    i = CW.synthetic_inputs(fx[f"{tag}_frames"], fx[f"{tag}_prompt"], seed=fx[f"{tag}_seed"])
+    z = torch.zeros_like(i["mu"])
+    got = cfm.estimator(torch.cat([i["noise"], i["noise"]]), torch.cat([i["mu"], z]), float(fx[f"{tag}_t"]),
+                        torch.cat([i["spks"], torch.zeros(1, 80)]), torch.cat([i["cond"], z]))
+    assert _rel(got, fx[f"{tag}_estimator_out"].double()) < 3e-5
+
+
+def test_solve_matches_the_reference_solve(cfm, fx):
+    """s3cfm_solve against the reference's CausalConditionalCFM.forward around its own estimator (flow_matching.py:203-228,
+    82-133), 10 steps, 40 frames."""
+    i = CW.synthetic_inputs(40, 12)
+    got = cfm.solve_euler(i["noise"], CW.t_span(10), i["mu"], i["spks"], i["cond"])
+    assert _rel(got, fx["b_forward_10"].double()) < 1e-4
 
 
 def test_solve_matches_the_restatement(cfm, sd):

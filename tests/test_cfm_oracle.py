@@ -1,11 +1,14 @@
 """CPU tests of the flow-matching decoder's restatement (oracle/cfm_oracle.py) and of the package's host side for it.
 
-The restatement is PARITY UNPINNED: the reference's modules for this stage import `diffusers` and `conformer`, which are
-not installed, and the reference holds no outputs of the stage.  These tests hold the restatement to properties the
-reference's source implies: the tensor inventory is the module tree of decoder.py:100-217, the convolutions are causal
-while attention is not, the guidance combination is linear in the two estimates, and the time grid is the cosine one."""
+The restatement is pinned by tests/golden/cfm_fixture.npz (made by tests/golden/make_cfm_fixtures.py from the reference's
+own decoder.py / matcha/decoder.py / matcha/transformer.py / flow_matching.py): part A holds outputs of the reference's own
+arithmetic alone, part B the whole estimator and solve with the three diffusers classes as labelled stand-ins, so what stays
+unpinned is the inside of those three classes.  The remaining tests hold the restatement to properties the source implies."""
 import math
 
+import os
+
+import numpy as np
 import pytest
 import torch
 
@@ -95,3 +98,85 @@ def test_flop_count():
     # per frame and row: 14 resnets, 56 transformer blocks (attention grows with the utterance), 3 tail / final convolutions
     f = CW.estimator_flop(1000)
     assert 4.5e11 < f < 5.5e11
+
+
+# ---- the restatement against outputs of the reference's own code (tests/golden/cfm_fixture.npz) ----------------------
+@pytest.fixture(scope="module")
+def fx():
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "cfm_fixture.npz"))
+    return {k: torch.from_numpy(z[k]) if z[k].ndim else z[k].item() for k in z.files}
+
+
+def _close(got, want, tol):
+    """|got - want| <= tol * max|want|."""
+    err = (got.double() - want.double()).abs().max().item()
+    assert err <= tol * want.abs().max().item(), f"{err:.3g} against a scale of {want.abs().max().item():.3g}"
+
+
+def test_time_embedding_equals_the_reference(fx):
+    # matcha/decoder.py:14-29 and 73-118 on this repository's seeded weights
+    sd = CW.synthetic_state_dict()
+    t = fx["a_posemb_t"]
+    _close(O.sinusoidal_pos_emb(t), fx["a_posemb_out"], 1e-6)
+    _close(O.time_embedding(sd, t), fx["a_temb_out"], 2e-6)
+
+
+def test_causal_convolution_block_and_resnet_block_equal_the_reference(fx):
+    # decoder.py:48-97, matcha/decoder.py:46-61.  The fixture's second row is padded from frame 29 on (mask 0): the
+    # restatement is written for an all-ones mask, and the blocks are causal, so it must agree on every frame before 29.
+    sd = CW.synthetic_state_dict()
+    P = CW.PREFIX
+    _close(O.causal_conv(sd, P + "down_blocks.0.2", fx["a_x256"]), fx["a_conv_out"], 2e-6)
+    got = O.causal_block(sd, P + "final_block.", fx["a_x256"])
+    _close(got[0], fx["a_block_out"][0], 2e-6)
+    _close(got[1, :, :29], fx["a_block_out"][1, :, :29], 2e-6)
+    assert fx["a_block_out"][1, :, 29:].abs().max() == 0
+    got = O.resnet_block(sd, P + "down_blocks.0.0.", fx["a_x320"], fx["a_resnet_temb"])
+    _close(got[0], fx["a_resnet_out"][0], 2e-6)
+    _close(got[1, :, :29], fx["a_resnet_out"][1, :, :29], 2e-6)
+
+
+def _closed_form(x, mu, t, spks, cond):
+    # tests/golden/make_cfm_fixtures.py::ClosedFormEstimator with an all-ones mask
+    return 0.5 * x - 0.25 * mu + torch.sin(3.0 * t)[:, None, None] + 0.125 * spks[:, :, None] * x + 0.0625 * cond
+
+
+def test_euler_solve_and_forward_equal_the_reference_around_a_closed_form_estimator(fx):
+    # flow_matching.py:82-133, 203-228: time grid, guidance batch (second row zeroed), rate 0.7, fp32 update order
+    inp = CW.synthetic_inputs(24, 7)
+    ts = CW.t_span(10)
+    assert torch.equal(ts, fx["a_euler_t_span"])
+    got = O.solve_euler(None, inp["noise"], ts, inp["mu"], inp["spks"], inp["cond"], estimator_fn=_closed_form)
+    _close(got, fx["a_euler_solve"], 1e-6)
+    for n, temp in ((10, 1.0), (4, 0.8)):
+        got = O.cfm_forward(None, inp["mu"], inp["spks"], inp["cond"], fx["a_euler_rand_noise"], n_timesteps=n,
+                            temperature=temp, estimator_fn=_closed_form)
+        _close(got, fx[f"a_euler_forward_{n}"], 1e-6)
+    # the recorded solve does depend on which row is zeroed: conditioning both rows gives something else
+    both = lambda x, mu, t, sp, c: _closed_form(x, torch.cat([mu[:1], mu[:1]]), t, torch.cat([sp[:1], sp[:1]]), torch.cat([c[:1], c[:1]]))
+    other = O.solve_euler(None, inp["noise"], ts, inp["mu"], inp["spks"], inp["cond"], estimator_fn=both)
+    assert (other - fx["a_euler_solve"]).abs().max() > 0.05
+
+
+def _fixture_rows(fx, tag):
+    i = CW.synthetic_inputs(fx[f"{tag}_frames"], fx[f"{tag}_prompt"], seed=fx[f"{tag}_seed"])
+    z = torch.zeros_like(i["mu"])
+    t = torch.full((2,), fx[f"{tag}_t"], dtype=torch.float32)
+    return (torch.cat([i["noise"], i["noise"]]), torch.cat([i["mu"], z]), t, torch.cat([i["spks"], torch.zeros(1, 80)]),
+            torch.cat([i["cond"], z]))
+
+
+@pytest.mark.parametrize("tag", ["b1", "b2"])
+def test_whole_estimator_equals_the_reference_module_tree(fx, tag):
+    # ConditionalDecoder.forward, decoder.py:233-317 (the three diffusers classes as the fixture's labelled stand-ins)
+    sd = CW.synthetic_state_dict()
+    x, mu, t, sp, c = _fixture_rows(fx, tag)
+    _close(O.estimator(sd, x, mu, t, sp, c), fx[f"{tag}_estimator_out"], 2e-5)
+    w = {k: v.double() for k, v in sd.items()}
+    _close(O.estimator(w, x.double(), mu.double(), t.double(), sp.double(), c.double()), fx[f"{tag}_estimator_out"], 2e-5)
+
+
+def test_ten_step_solve_equals_the_reference(fx):
+    sd = CW.synthetic_state_dict()
+    i = CW.synthetic_inputs(40, 12)
+    _close(O.cfm_forward(sd, i["mu"], i["spks"], i["cond"], i["noise"]), fx["b_forward_10"], 5e-5)

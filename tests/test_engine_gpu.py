@@ -4,10 +4,12 @@ T3Engine -> ctypes -> libt3hip.so.
 Bar: greedy ids, with a stated tolerance on logits (tests/parity_bar.py).  The engine and the oracle both round
 every op output to bf16 but sum in different orders, so a logit can differ by a few bf16 ulp.
 
-  * On the DECISIVE checkpoint (weights.decisive_state_dict: every step's top-2 margin is at least 3 tolerances)
-    the engine's ids must EQUAL the oracle's for whole sequences: the committed goldens at 2 and 30 layers
-    (>= 4 requests x >= 64 tokens x the three stream modes), live oracle runs at long contexts, int8 weights and
-    mixed multilingual batches.
+  * On the DECISIVE checkpoint (weights.decisive_state_dict: the winner of a step is picked by layer-0 attention
+    over the paged history at fixed rotary distances, by the text rows and by the cond / uncond pairing, with top-2
+    margins of at least 3 tolerances) the engine's ids must EQUAL the oracle's for whole sequences: the committed
+    goldens at 2 and 30 layers (>= 4 requests x >= 64 tokens x the three stream modes, whose ids differ from each
+    other within 16 steps and change when a KV page is lost), a 30-layer golden across position 512 with full logit
+    rows, live oracle runs at long contexts and mixed multilingual batches.
   * On the FLAT checkpoint (synthetic_state_dict: 8194 nearly Gaussian logits, top-2 gaps of a few ulp, so two
     correct implementations may pick differently) the oracle is run teacher-forced on the engine's ids and every
     step must satisfy |engine logit - oracle logit| <= TOL; the engine's id must be the oracle's argmax whenever the
@@ -181,6 +183,7 @@ def test_ids_do_not_depend_on_batch_or_scheduling(small):
     assert run(16, False)[0] == base                        # HIP graph replay
     assert run(3, False)[0] == base                         # continuous batching, 3 slots
     assert run(3, False, policy="longest_first")[0] == base # another admission order, results in input order
+    assert run(3, False, policy="longest_prompt_first")[0] == base
     for i in (0, 4, 7):
         assert run(1, True, [i])[0][0] == base[i]           # alone
 
@@ -636,6 +639,66 @@ def test_engine_ids_equal_the_decisive_oracle_goldens(case):
             compared += len(got_ids)
             long_requests += int(len(got_ids) >= 64)
     assert long_requests >= 12 and compared >= 3 * 250, f"{compared} ids of {long_requests} long sequences compared"
+    # what the equality above is worth: in the golden the three modes' ids differ from each other within 16 steps
+    for req in reqs:
+        assert all(d is not None and d < 16 for d in req["modes_first_differ_at"].values())
+
+
+@pytest.mark.parametrize("case", ["decisive_micro", "decisive_full"])
+def test_a_wrong_stream_mode_cannot_reproduce_the_goldens(case):
+    """The decisive checkpoint's walk is decided by attention over the paged history, by the text rows and by the cond /
+    uncond pairing, so an engine run in one stream mode must LEAVE the golden ids of each other mode within the first 16
+    steps, for every request (and equal its own mode's: the test above).  This is what makes the id equality a check of
+    the pairing semantics, the uncond stream's KV and the CFG combine."""
+    with open(os.path.join(os.path.dirname(__file__), "golden", "oracle_golden.json")) as f:
+        gold = json.load(f)[case]
+    cfg = T3ModelConfig.english(n_layers=gold["n_layers"])
+    sd = W.decisive_state_dict(cfg)
+    sp = SamplingParams(temperature=0.0, repetition_penalty=2.0, max_tokens=16, stop_token_ids=[STOP])
+    reqs = gold["requests"]
+    items = _items([r["text_ids"] for r in reqs], [r["voice"] for r in reqs])
+    for mode, kw in _MODES.items():
+        s = gold["cfg_scale"] if kw["cfg_paired"] else 0.0
+        eng = T3Engine(cfg, sd, max_model_len=gold["max_model_len"], max_num_seqs=len(reqs), cfg_scale=s, **kw)
+        ids = [o.outputs[0].token_ids for o in eng.generate(items, sp)]
+        eng.shutdown()
+        for req, got in zip(reqs, ids):
+            assert got == req["modes"][mode]["token_ids"][:len(got)]
+            for other in _MODES:
+                if other != mode:
+                    assert got != req["modes"][other]["token_ids"][:len(got)], f"{mode} reproduces the ids of {other}"
+
+
+def test_long_context_30_layers_equals_the_golden():
+    """tests/golden/long_context_golden.npz: 30 layers, the decisive checkpoint with look-back distances 5, 37, 150 and 400,
+    a 478-id text (515-position prompt) decoded across positions 515..586: ten KV pages per stream, two 8-tile rounds per
+    attention wave, several query tiles in the prefill.  Every step of the golden is decisive, so the engine's 72 ids must
+    EQUAL the golden's (eager with logit taps, and again by graph replay beside another request), and all 8194 logits of
+    the ten recorded steps must lie within the tolerance."""
+    import numpy as np
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "long_context_golden.npz"))
+    L, s = int(z["n_layers"]), float(z["cfg_scale"])
+    cfg = T3ModelConfig.english(n_layers=L)
+    sd = W.decisive_state_dict(cfg, groups=W.DECISIVE_GROUPS_LONG)
+    row_scale = PB.head_row_scale(sd)
+    tol = PB.logit_tol(s, L)
+    text, voice, want = z["text_ids"].tolist(), int(z["voice"]), z["token_ids"].tolist()
+    assert len(build_prompt_ids(text)) == 515
+    eng = T3Engine(cfg, sd, max_model_len=int(z["max_model_len"]), max_num_seqs=2, cfg_scale=s)
+    sp = SamplingParams(temperature=0.0, repetition_penalty=2.0, max_tokens=int(z["max_tokens"]), stop_token_ids=[STOP])
+    ids, logits, _ = _run_with_logits(eng, _items([text], [voice]), sp)
+    plain = eng.generate(_items([text, _text(30, 5)], [voice, 0]), sp)
+    eng.shutdown()
+    assert ids[0] == want, "ids differ from the long-context golden"
+    assert plain[0].outputs[0].token_ids == want
+    worst = 0.0
+    for step, row in zip(z["logit_steps"], torch.from_numpy(z["logit_rows"])):
+        got = logits[0][step][1000:]
+        fin = torch.isfinite(row)
+        d = ((got[fin] - row[fin]).abs() / PB.tol_at(row[fin], tol, row_scale[1000:][fin])).max().item()
+        worst = max(worst, d)
+        assert d <= 1.0, f"step {step}: a logit is off by {d:.2f} tolerances"
+    print(f"long-context golden: worst logit error {worst:.2f} tolerances over {len(z['logit_steps'])} full rows")
 
 
 def _check_decisive(oracle, ids, logits, text, cond, max_tokens, max_model_len, paired, cfg_scale, min_decisive=0.9,
@@ -806,9 +869,21 @@ def test_non_finite_conditioning_is_reported_not_a_fault(small):
     want = eng.generate(good, sp)[0].outputs[0].token_ids
     bad = W.synthetic_cond_emb(3).clone()
     bad[5, 100] = float("nan")
-    with pytest.raises(T3Error):
+    with pytest.raises(T3Error) as ei:
         eng.generate([{"prompt_token_ids": _text(7, 2), "multi_modal_data": {"conditionals": [bad]}}] + good, sp)
     assert not eng.has_unfinished()
+    # the healthy request of the same call ran to its end and travels with the error
+    failed, healthy = ei.value.outputs
+    assert failed.outputs[0].finish_reason == "error" and healthy.outputs[0].token_ids == want
+    # a serving loop that steps by itself sees the failure as a finish reason, next to the other requests' tokens
+    eng.add_request(_text(7, 2), bad, sp, request_id=900)
+    eng.add_request(_text(5, 1), W.synthetic_cond_emb(0), sp, request_id=901)
+    seen = {900: [], 901: []}
+    while eng.has_unfinished():
+        for rid, tok, fin in eng.step():
+            seen[rid].append((tok, fin))
+    assert [f for _, f in seen[900]] == ["error"]
+    assert [t for t, _ in seen[901]] == want and seen[901][-1][1] == "length"
     sampled = SamplingParams(temperature=0.8, top_p=0.9, repetition_penalty=2.0, max_tokens=3, seed=1)
     with pytest.raises(T3Error):
         eng.generate([{"prompt_token_ids": _text(7, 2), "multi_modal_data": {"conditionals": [bad]}}], sampled)

@@ -771,3 +771,45 @@ def test_tile_ordered_activations_give_the_same_bits(capi, M):
     call(capi, "t3_op_slab_add_rmsnorm_tiled", p(slabs[0]), S, p(r2), p(g), p(xn2), M, 1024, C.c_float(1e-5), None)
     torch.cuda.synchronize()
     assert torch.equal(r1, r2) and torch.equal(_untile_act(xn2, M, 1024), xn1)
+
+
+@pytest.mark.parametrize("M", [1, 130, 512, 513, 1300])
+def test_prompt_gemm_forms_give_the_same_bits(capi, M):
+    """The row-walking prompt kernel (one workgroup per weight tile, all rows; every weight byte fetched once) against the
+    kernel with one workgroup per 128-row tile: gate_up + SiLU, split-K slabs at K = 1024 and 4096, QKV + RoPE + cache
+    write, bf16 weights; outputs and KV pool must be bit-identical (both accumulate an output in k order in one accumulator)."""
+    cfg = T3ModelConfig.english()
+    H, hd, K, F = 16, 64, 1024, 4096
+    a = _rand((M, K), 80).to(DEV)
+    wgu = repack(capi, _rand((2 * F, K), 81, 0.05).to(DEV))
+    wo = repack(capi, _rand((1024, K), 82, 0.05).to(DEV))
+    a4 = _rand((M, 4096), 83).to(DEV)
+    wd = repack(capi, _rand((1024, 4096), 84, 0.03).to(DEV))
+    wqkv = repack(capi, _rand((3 * H * hd, K), 85, 0.03).to(DEV))
+    rope = W.rope_table(cfg, 1000).to(DEV)
+    n_streams, max_pages = 8, 16
+    stream = (torch.arange(M) % n_streams).to(torch.int32)
+    pos = (torch.arange(M) // n_streams).to(torch.int32)
+    S = capi.t3_op_slab_split()
+    out = {}
+    try:
+        for walk in (1, 0):
+            call(capi, "t3_op_set_prompt_gemm_form", walk)
+            h = torch.zeros(M, F, dtype=torch.bfloat16, device=DEV)
+            call(capi, "t3_op_gemm_prompt_silu", p(a), p(wgu), p(h), M, F, K, None)
+            s1 = torch.zeros(S, M, 1024, dtype=torch.float32, device=DEV)
+            call(capi, "t3_op_gemm_prompt_slab", p(a), p(wo), C.cast(p(s1), C.POINTER(C.c_float)), M, 1024, K, None)
+            s4 = torch.zeros(S, M, 1024, dtype=torch.float32, device=DEV)
+            call(capi, "t3_op_gemm_prompt_slab", p(a4), p(wd), C.cast(p(s4), C.POINTER(C.c_float)), M, 1024, 4096, None)
+            pool, bt, layer_stride = _kv_setup(n_streams, max_pages, 1, seed=3)
+            qkv = torch.zeros(M, 3 * H * hd, dtype=torch.bfloat16, device=DEV)
+            btd, posd, std = bt.to(DEV), pos.to(DEV), stream.to(DEV)
+            call(capi, "t3_op_gemm_prompt_qkv_rope", p(a), p(wqkv), p(qkv), M, H, hd, K, p(rope), p(posd), p(std), p(pool),
+                 layer_stride, 0, p(btd), max_pages, None)
+            torch.cuda.synchronize()
+            out[walk] = (h, s1, s4, qkv, pool)
+    finally:
+        call(capi, "t3_op_set_prompt_gemm_form", 0)
+    for x, y, what in zip(out[1], out[0], ("gate_up", "o slab", "down slab", "qkv", "kv pool")):
+        assert torch.equal(x, y), f"{what}: the two prompt forms differ at M = {M}"
+    assert out[1][0].abs().sum() > 0 and out[1][4].abs().sum() > 0

@@ -106,8 +106,10 @@ class _StandInEngine:
         return [self._wave(prompts, diffusion_steps)]
 
     def generate_with_conds(self, prompts, s3gen_ref, cond_emb, language_id="en", temperature=0.8, exaggeration=0.5,
-                            max_tokens=1000, top_p=1.0, per_prompt_max_tokens=False, tokens_only=False, **kw):
+                            max_tokens=1000, top_p=1.0, per_prompt_max_tokens=False, tokens_only=False, per_prompt_clamp=False,
+                            **kw):
         assert tokens_only and per_prompt_max_tokens and top_p == 0.8
+        assert per_prompt_clamp == isinstance(language_id, list)
         self.calls.append(("tokens", list(prompts), max_tokens, language_id))
         return [torch.tensor([ord(ch) for ch in p]) for p in prompts]
 
@@ -190,7 +192,16 @@ def test_language_fallback_applies_to_the_multilingual_engine_only():
     assert eng.calls[-1][4] == "fr"
     svc.synthesize("plain ascii", language_id=None)
     assert eng.calls[-1][4] is None
-    # the streamed form detects once, on the whole text, and uses it for every chunk
+    # the streamed form resolves the language chunk by chunk, as the reference's per-chunk _synthesize_one calls do
+    # (openai_tts_server.py:406-411, 501-509): one language for a one-script text ...
+    eng.calls.clear()
     list(svc.stream_waveforms("你好，世界。今天天气很好！我们去公园散步吧。", language_id="", first_chunk_chars=10, chunk_chars=40))
-    langs = {c[-1] for c in eng.calls if c[0] in ("generate", "tokens")} - {None, "ru", "fr"}
-    assert langs == {"zh"}
+    first = [c for c in eng.calls if c[0] == "generate"][0]
+    rest = [c for c in eng.calls if c[0] == "tokens"][0]
+    assert first[-1] == "zh" and set(rest[-1]) == {"zh"} and len(rest[-1]) == len(rest[1])
+    # ... and each chunk's own for mixed scripts: an English first chunk keeps no language, the Hebrew one gets "he"
+    eng.calls.clear()
+    list(svc.stream_waveforms("Hello there my friend. שלום עולם, מה שלומך היום?", language_id=None, first_chunk_chars=25, chunk_chars=60))
+    first = [c for c in eng.calls if c[0] == "generate"][0]
+    rest = [c for c in eng.calls if c[0] == "tokens"][0]
+    assert first[-1] is None and rest[-1] == [S.detect_language(c) for c in rest[1]] and "he" in rest[-1]

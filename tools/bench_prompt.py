@@ -16,13 +16,15 @@ def main():
     lib = _capi.load()
     dev = "cuda:0"
     S = lib.t3_op_slab_split()
-    rows = [int(x) for x in sys.argv[1:]] or [128, 512, 1024]
+    rows = [int(x) for x in sys.argv[1:] if x.isdigit()] or [128, 512, 1024]
+    forms = [0, 1] if "--both" in sys.argv else [0]
     cases = {"gateup_silu N=8192 K=1024": (8192, 1024, "silu"), "qkv-shaped silu N=3072 K=1024": (3072, 1024, "silu"),
              "down slab N=1024 K=4096": (1024, 4096, "slab"), "o slab N=1024 K=1024": (1024, 1024, "slab")}
     for name, (N, K, kind) in cases.items():
         ncopies = 8
         ws = [torch.randn(N, K, device=dev, dtype=torch.bfloat16) * 0.02 for _ in range(ncopies)]
-        for M in rows:
+        for M, form in ((m, f) for m in rows for f in forms):
+            _capi.check(lib, lib.t3_op_set_prompt_gemm_form(form))
             x = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
             out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
             slab = torch.empty(S, M, N, device=dev, dtype=torch.float32)
@@ -45,7 +47,7 @@ def main():
                 g.replay()
             torch.cuda.synchronize()
             us = (time.perf_counter() - t0) / (10 * L) * 1e6
-            print(f"{name:32s} rows={M:5d}  {us:7.2f} us  {2.0 * M * N * K / us / 1e6:7.1f} TFLOP/s", flush=True)
+            print(f"{name:32s} {'row-walking' if form else 'tile per workgroup':18s} rows={M:5d}  {us:7.2f} us  {2.0 * M * N * K / us / 1e6:7.1f} TFLOP/s", flush=True)
 
 
 if __name__ == "__main__":

@@ -67,7 +67,6 @@ DECISIVE_QK = 3.5             # q and k weight on the tag coordinate: peak score
 DECISIVE_GROUPS = ((5, 1, 1.0), (37, 2, 1.0))                      # (look-back distance, slice written, amplitude)
 # head weights of the edges: first (strong, weak source), near, far (speech source, text source); 1 is a logit of 18.3
 DECISIVE_LEVELS = (1.57, 0.71, 1.05, 0.85, 0.85)
-DECISIVE_GROUPS_LONG = DECISIVE_GROUPS + ((150, 2, 0.8), (400, 2, 0.65))
 
 
 def _sylvester(n: int) -> torch.Tensor:
@@ -96,7 +95,7 @@ def decisive_state_dict(cfg: T3ModelConfig, seed: int = 1234, groups=DECISIVE_GR
       coordinate in the 8 fastest rotary pairs, with the key pre-rotated by ``delta_g`` positions, so after RoPE the
       score is ``sum_j 12.3 cos((p - s - delta_g) theta_j)``: 98 at the row ``delta_g`` back, 88 next to it, below 75
       elsewhere.  v copies the code coordinates, o writes them (scaled) into residual slice 1 (``delta = 5``) or slice
-      2 (``delta = 37``; ``DECISIVE_GROUPS_LONG`` adds 150 and 400 for long contexts).  Rows that are not structured
+      2 (``delta = 37``).  Rows that are not structured
       (the 34 conditioning rows: random tag; the zeroed text rows of the uncond stream: no key at all) are poor keys,
       so a look-back that lands on them settles on another row.  Everything here is exact in bf16 or taken from one
       coordinate, so two implementations form bit-identical scores.

@@ -670,8 +670,8 @@ def test_a_wrong_stream_mode_cannot_reproduce_the_goldens(case):
 
 
 def test_long_context_30_layers_equals_the_golden():
-    """tests/golden/long_context_golden.npz: 30 layers, the decisive checkpoint with look-back distances 5, 37, 150 and 400,
-    a 478-id text (515-position prompt) decoded across positions 515..586: ten KV pages per stream, two 8-tile rounds per
+    """tests/golden/long_context_golden.npz: 30 layers, the decisive checkpoint,
+    a 478-id text (513-position prompt) decoded across positions 513..584: ten KV pages per stream, two 8-tile rounds per
     attention wave, several query tiles in the prefill.  Every step of the golden is decisive, so the engine's 72 ids must
     EQUAL the golden's (eager with logit taps, and again by graph replay beside another request), and all 8194 logits of
     the ten recorded steps must lie within the tolerance."""
@@ -679,11 +679,11 @@ def test_long_context_30_layers_equals_the_golden():
     z = np.load(os.path.join(os.path.dirname(__file__), "golden", "long_context_golden.npz"))
     L, s = int(z["n_layers"]), float(z["cfg_scale"])
     cfg = T3ModelConfig.english(n_layers=L)
-    sd = W.decisive_state_dict(cfg, groups=W.DECISIVE_GROUPS_LONG)
+    sd = W.decisive_state_dict(cfg)
     row_scale = PB.head_row_scale(sd)
     tol = PB.logit_tol(s, L)
     text, voice, want = z["text_ids"].tolist(), int(z["voice"]), z["token_ids"].tolist()
-    assert len(build_prompt_ids(text)) == 515
+    assert len(build_prompt_ids(text)) == 513
     eng = T3Engine(cfg, sd, max_model_len=int(z["max_model_len"]), max_num_seqs=2, cfg_scale=s)
     sp = SamplingParams(temperature=0.0, repetition_penalty=2.0, max_tokens=int(z["max_tokens"]), stop_token_ids=[STOP])
     ids, logits, _ = _run_with_logits(eng, _items([text], [voice]), sp)

@@ -615,6 +615,12 @@ def test_engine_ids_equal_the_decisive_oracle_goldens(case):
     reqs = gold["requests"]
     items = _items([r["text_ids"] for r in reqs], [r["voice"] for r in reqs])
     compared, long_requests = 0, 0
+    # 30 layers only: ALL 8194 speech logits of every eighth step of one request per mode (decisive_full_rows.npz,
+    # written by the oracle from the same checkpoint), so the tolerance is held over whole rows, not the 8-wide slices
+    full_rows = None
+    if case == "decisive_full":
+        import numpy as np
+        full_rows = np.load(os.path.join(os.path.dirname(__file__), "golden", "decisive_full_rows.npz"))
     for mode, kw in _MODES.items():
         s = gold["cfg_scale"] if kw["cfg_paired"] else 0.0
         tol = PB.logit_tol(s, L)
@@ -622,6 +628,15 @@ def test_engine_ids_equal_the_decisive_oracle_goldens(case):
         ids, logits, fins = _run_with_logits(eng, items, sp)
         plain = eng.generate(items, sp)
         eng.shutdown()
+        if full_rows is not None:
+            k, worst = int(full_rows[f"{mode}_request"]), 0.0
+            for step, row in zip(full_rows[f"{mode}_steps"], torch.from_numpy(full_rows[f"{mode}_rows"])):
+                fin = torch.isfinite(row)
+                got = logits[k][step][1000:]
+                d = ((got[fin] - row[fin]).abs() / PB.tol_at(row[fin], tol, row_scale[1000:][fin])).max().item()
+                worst = max(worst, d)
+                assert d <= 1.0, f"{mode} request {k} step {step}: a logit of the full row is off by {d:.2f} tolerances"
+            print(f"{mode}: worst logit error {worst:.2f} tolerances over {len(full_rows[f'{mode}_steps'])} full rows")
         for k, (req, got_ids, got_logits, fin, po) in enumerate(zip(reqs, ids, logits, fins, plain)):
             g = req["modes"][mode]
             for t, (margin, top, sc) in enumerate(zip(g["margins"], g["top_logit"], g["top2_row_scale"])):
@@ -928,3 +943,26 @@ def test_bench_launches_two_ranks_by_itself():
     assert rec["n_gpus"] == 2 and rec["ranks_seen"] == 2 and rec["data"] == "synthetic"
     assert rec["config"]["requests_per_gpu"] == 8 and rec["value"] > 0
     assert abs(rec["per_gpu_tokens_per_s"] * 2 - rec["value"]) < 1.0
+
+
+def test_bench_runs_its_rccl_collectives_with_one_rank():
+    """bench.py under torch.distributed.run with ONE rank and --force-dist: the process group is RCCL (backend "nccl"), and the
+    weight broadcast, the max / sum all-reduces and the all-gather of the ids run through it on the GPU, as they do with 2,
+    4 or 8 ranks (this box has one GPU; the multi-rank launcher itself is covered by the gloo test above)."""
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist",
+                        "--layers", "2", "--requests", "8", "--steps", "1", "--warmup", "0", "--no-roofline", "--no-cpu-baseline",
+                        "--no-extra-legs"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert p.returncode == 0, p.stderr[-3000:]
+    rec = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["n_gpus"] == 1 and rec["ranks_seen"] == 1 and rec["value"] > 0 and rec["config"]["requests_per_gpu"] == 8

@@ -21,6 +21,7 @@ _SIGNATURES = {
     "s3cfm_destroy": ([_P], C.c_int),
     "s3cfm_load_tensor": ([_P, C.c_char_p, _P, C.POINTER(C.c_int64), C.c_int32], C.c_int),
     "s3cfm_finalize": ([_P], C.c_int),
+    "s3cfm_set_split_bf16": ([_P, C.c_int32], C.c_int),
     "s3cfm_estimator": ([_P, _P, _P, _P, _P, C.c_float, C.c_int32, _P, _P], C.c_int),
     "s3cfm_solve": ([_P, _P, _P, _P, _P, C.c_int32, C.POINTER(C.c_float), C.c_int32, C.c_double, _P, _P], C.c_int),
     "s3cfm_solve_batch": ([_P, C.c_int32, C.POINTER(C.c_int32), C.c_int32, _P, _P, _P, _P, C.POINTER(C.c_float), C.c_int32, C.c_double, _P,
@@ -28,6 +29,8 @@ _SIGNATURES = {
     "s3cfm_op_linear": ([_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, C.c_int32,
                          _P, _P, C.c_int32, C.POINTER(C.c_float), _P], C.c_int),
     "s3cfm_op_attention": ([_P, _P, C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int32, _P, C.c_int32, C.POINTER(C.c_float), _P], C.c_int),
+    "s3cfm_op_attention_split": ([_P, _P, C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int32, _P, C.c_int32, C.POINTER(C.c_float),
+                                  C.POINTER(C.c_float), _P], C.c_int),
 }
 
 VT_LD = 576                  # row stride of the frame-major V tensor (512 channels + padding)
@@ -54,10 +57,15 @@ class CausalConditionalCFM:
     unless one is passed.
 
     ``max_batch`` > 1 gives the workspace room for that many utterances per ``forward_batch`` call (no counterpart in the
-    reference, which runs one utterance per call)."""
+    reference, which runs one utterance per call).
+
+    ``split_bf16`` (no counterpart in the reference either; off by default): the attention launches hold every fp32 operand
+    as three bf16 values and take six partial products per product on the bf16 matrix instruction, fp32 accumulation; the
+    results stay within the fp32 form's distance of an fp64 computation (``set_split_bf16`` switches it later)."""
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], max_frames: int = 3000, device: int = 0,
-                 inference_cfg_rate: float = CW.CFG_RATE, generator: Optional[torch.Generator] = None, max_batch: int = 1):
+                 inference_cfg_rate: float = CW.CFG_RATE, generator: Optional[torch.Generator] = None, max_batch: int = 1,
+                 split_bf16: bool = False):
         self._lib = _lib()
         self.device = torch.device("cuda", device)
         self.max_frames = max_frames
@@ -76,9 +84,16 @@ class CausalConditionalCFM:
                 shape = (C.c_int64 * t.dim())(*t.shape)
                 check(self._lib, self._lib.s3cfm_load_tensor(h, name.encode(), C.c_void_p(t.data_ptr()), shape, t.dim()))
             check(self._lib, self._lib.s3cfm_finalize(h))
+            self.split_bf16 = False
+            if split_bf16:
+                self.set_split_bf16(True)
         except Exception:
             self.shutdown()
             raise
+
+    def set_split_bf16(self, on: bool) -> None:
+        check(self._lib, self._lib.s3cfm_set_split_bf16(self._h, int(bool(on))))
+        self.split_bf16 = bool(on)
 
     def _check_len(self, L: int) -> None:
         if L < 1 or L > self.max_frames:
@@ -208,10 +223,12 @@ def linear_op(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, pad: int = 0
     return y_full[:, :, :L], (None if vt_full is None else vt_full[:, :L, :512]), us.value
 
 
-def attention_op(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, iters: int = 0, keys: Optional[Sequence[int]] = None):
+def attention_op(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, iters: int = 0, keys: Optional[Sequence[int]] = None,
+                 split: bool = False):
     """``s3cfm_op_attention`` on q, k, v [2 n, 512, L] (channel-major, head h in channels 64 h ..; rows 2 u and 2 u + 1 belong
     to utterance u, whose first ``keys[u]`` frames are real): returns (o [2 n, 512, L], average microseconds of `iters`
-    launches)."""
+    launches).  ``split``: ``s3cfm_op_attention_split`` (operands as bf16 triples); the time returned is then the pair
+    (attention launch, operand re-arrangement launch)."""
     lib = _lib()
     L, rows = q.shape[2], q.shape[0]
     assert rows % 2 == 0 and rows // 2 <= MAX_BATCH
@@ -227,5 +244,10 @@ def attention_op(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, iters: int =
     o = torch.zeros(rows, 512, ld, dtype=torch.float32, device=dev)
     us = C.c_float(0)
     lens = None if keys is None else (C.c_int32 * (rows // 2))(*[int(v) for v in keys])
+    if split:
+        us2 = C.c_float(0)
+        check(lib, lib.s3cfm_op_attention_split(_ptr(qk), _ptr(vt), rows // 2, lens, L, ld, _ptr(o), iters, C.byref(us), C.byref(us2),
+                                                _stream_ptr(dev)))
+        return o[:, :, :L], (us.value, us2.value)
     check(lib, lib.s3cfm_op_attention(_ptr(qk), _ptr(vt), rows // 2, lens, L, ld, _ptr(o), iters, C.byref(us), _stream_ptr(dev)))
     return o[:, :, :L], us.value

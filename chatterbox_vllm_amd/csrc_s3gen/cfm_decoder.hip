@@ -9,6 +9,7 @@
 // time-embedding add that follow it in a resnet block, is one small kernel.  Attention (8 heads x 64) is one launch with an
 // online softmax (attn_kernel).
 #include "hift_common.h"
+#include "cfm_split.h"
 #include "../../include/s3cfm_hip.h"
 
 #include <algorithm>
@@ -550,6 +551,8 @@ struct s3cfm {
     float *emb = nullptr, *th = nullptr, *temb = nullptr, *tvec = nullptr;
     float *IN = nullptr, *X = nullptr, *Y = nullptr, *Z = nullptr, *CAT = nullptr, *QK = nullptr, *VT = nullptr, *O = nullptr, *H = nullptr,
           *D = nullptr;
+    bool split = false;                                        // attention on split-bf16 operands (s3cfm_set_split_bf16)
+    unsigned short *QP = nullptr, *KP = nullptr, *VP = nullptr;     // its operand tensors (cfm_split.h), allocated on first use
 };
 
 namespace {
@@ -727,9 +730,16 @@ int run_transformer(s3cfm* h, const Transformer& b, int L, hipStream_t st) {
     const int ld = h->ld;
     // norm1 rides in the q/k/v projection (LinArgs::rsum); q and k channel-major into QK, v frame-major into VT
     if (run_lin(h, b.qkv, h->X, kC, h->QK, 2 * kInner, L, 0, OUT_NONE, nullptr, st, h->VT, 2 * kInner, b.qkv_rsum)) return 1;
-    AttnArgs at{h->QK, h->QK + (size_t)kInner * ld, (size_t)2 * kInner * ld, ld, h->VT, (size_t)ld * kVtLd, h->O, (size_t)kInner * ld, L, h->rows, {}};
-    for (int u = 0; u < kMaxUtt; ++u) at.Lk[u] = h->Lk[u];
-    if (launch_attn(at, st)) return 1;
+    if (h->split) {
+        if (launch_split_qkv(h->QK, (size_t)2 * kInner * ld, h->VT, (size_t)ld * kVtLd, kVtLd, ld, h->rows, h->QP, h->KP, h->VP, st)) return 1;
+        SplitAttnArgs sa{h->QP, h->KP, h->VP, h->O, (size_t)kInner * ld, ld, L, h->rows, {}};
+        for (int u = 0; u < kMaxUtt; ++u) sa.Lk[u] = h->Lk[u];
+        if (launch_attn_split(sa, st)) return 1;
+    } else {
+        AttnArgs at{h->QK, h->QK + (size_t)kInner * ld, (size_t)2 * kInner * ld, ld, h->VT, (size_t)ld * kVtLd, h->O, (size_t)kInner * ld, L, h->rows, {}};
+        for (int u = 0; u < kMaxUtt; ++u) at.Lk[u] = h->Lk[u];
+        if (launch_attn(at, st)) return 1;
+    }
     if (run_lin(h, b.out, h->O, kInner, h->X, kC, L, 0, OUT_NONE, h->X, st)) return 1;
     // norm3 rides in the first feed-forward layer
     if (run_lin(h, b.w1, h->X, kC, h->H, kFf, L, 0, OUT_GELU, nullptr, st, nullptr, 0, b.w1_rsum)) return 1;
@@ -881,6 +891,23 @@ extern "C" int s3cfm_finalize(s3cfm* h) {
     S3_HIP_CHECK(hipDeviceSynchronize());
     h->raw.clear();
     h->finalized = true;
+    return 0;
+}
+
+extern "C" int s3cfm_set_split_bf16(s3cfm* h, int32_t on) {
+    S3_REQUIRE(h && h->finalized, "handle not finalized");
+    S3_HIP_CHECK(hipSetDevice(h->device));
+    S3_HIP_CHECK(hipDeviceSynchronize());
+    if (on && !h->QP) {
+        const size_t bytes = (size_t)kRows * h->max_batch * 3 * kInner * h->ld * sizeof(unsigned short);
+        for (unsigned short** p : {&h->QP, &h->KP, &h->VP}) {
+            S3_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(p), bytes));
+            h->owned.push_back(*p);
+            S3_HIP_CHECK(hipMemset(*p, 0, bytes));
+        }
+        S3_HIP_CHECK(hipDeviceSynchronize());
+    }
+    h->split = on != 0;
     return 0;
 }
 

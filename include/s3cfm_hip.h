@@ -38,6 +38,13 @@ int s3cfm_destroy(s3cfm* h);
 int s3cfm_load_tensor(s3cfm* h, const char* name, const float* host_data, const int64_t* shape, int32_t ndim);
 int s3cfm_finalize(s3cfm* h);
 
+/* Arithmetic of the attention launches (no counterpart in the reference, which computes in fp32): on = 0, the default, takes
+ * every product on the fp32 matrix instruction; on = 1 holds each fp32 operand as three bf16 values whose sum is the operand
+ * and takes six partial products per product on the bf16 matrix instruction with fp32 accumulation (what is left out is
+ * below 2^-24 of a product, so results stay as close to fp64 as the fp32 form's; the launch is 1.7x shorter at 1 000 frames).
+ * Allocates 9 KiB of workspace per frame and utterance on first use; synchronises the device. */
+int s3cfm_set_split_bf16(s3cfm* h, int32_t on);
+
 /* One estimator call, `ConditionalDecoder.forward(x, mask, mu, t, spks, cond)` (decoder.py:233-317) on two rows:
  * x_dev, mu_dev, cond_dev [2][80][L], spks_dev [2][80], the same time t for both rows (as solve_euler calls it,
  * flow_matching.py:116) -> out_dev [2][80][L]. */
@@ -85,6 +92,13 @@ int s3cfm_op_linear(const float* x_dev, int32_t Cin, int32_t L, int32_t ld, cons
  * the outputs of queries past them are unspecified but finite, as s3cfm_solve_batch uses it. */
 int s3cfm_op_attention(const float* qk_dev, const float* vt_dev, int32_t n_utt, const int32_t* keys, int32_t L, int32_t ld, float* o_dev,
                        int32_t iters, float* avg_us, void* stream);
+
+/* The same attention with every fp32 operand held as three bf16 values whose sum is the operand and every product taken
+ * as six partial products on the bf16 matrix instruction (fp32 accumulation; what is left out is below 2^-24 of a product):
+ * a launch that re-arranges q, k, v into matrix-operand order (timed into split_avg_us), then the attention launch
+ * (attn_avg_us).  Same arguments and result layout as s3cfm_op_attention; ld must be a multiple of 32. */
+int s3cfm_op_attention_split(const float* qk_dev, const float* vt_dev, int32_t n_utt, const int32_t* keys, int32_t L, int32_t ld,
+                             float* o_dev, int32_t iters, float* attn_avg_us, float* split_avg_us, void* stream);
 
 #ifdef __cplusplus
 }

@@ -23,10 +23,14 @@ def sd():
     return CW.synthetic_state_dict()
 
 
-@pytest.fixture(scope="module")
-def cfm(sd):
+# every test of the decoder runs in both arithmetic forms of the attention launches, to the same tolerances
+_FORMS = dict(params=[False, True], ids=["fp32", "split_bf16"])
+
+
+@pytest.fixture(scope="module", **_FORMS)
+def cfm(sd, request):
     from chatterbox_vllm_amd.cfm_decoder import CausalConditionalCFM
-    m = CausalConditionalCFM(sd, max_frames=700, generator=torch.Generator().manual_seed(3))
+    m = CausalConditionalCFM(sd, max_frames=700, generator=torch.Generator().manual_seed(3), split_bf16=request.param)
     yield m
     m.shutdown()
 
@@ -219,24 +223,27 @@ def test_qkv_projection_writes_v_frame_major():
     assert (vt.double().cpu() - want[:, 1024:].transpose(1, 2)).abs().max().item() < 1e-5
 
 
+@pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("L", [1, 31, 32, 100, 129, 1000, 1100, 2101])
-def test_attention_kernel_against_fp64(L):
+def test_attention_kernel_against_fp64(L, split):
     """softmax(q k^T / 8) v per head against fp64, lengths around the 32-key tile and the four-wave split, with score
     spreads of tens of units so that the running maximum moves; 1000, 1100 and 2101 frames make the launcher pick two,
-    three and one query tiles per wave."""
+    three and one query tiles per wave.  split: the form that holds every operand as three bf16 values and takes six partial
+    products per product on the bf16 matrix instruction, to the same tolerance."""
     from chatterbox_vllm_amd.cfm_decoder import attention_op
     g = torch.Generator().manual_seed(L)
     q = 2.0 * torch.randn(2, 512, L, generator=g)
     k = 2.0 * torch.randn(2, 512, L, generator=g)
     v = torch.randn(2, 512, L, generator=g)
-    o, _ = attention_op(q.cuda(), k.cuda(), v.cuda())
+    o, _ = attention_op(q.cuda(), k.cuda(), v.cuda(), split=split)
     qh, kh, vh = (t.double().view(2, 8, 64, L) for t in (q, k, v))
     a = torch.softmax(qh.transpose(2, 3) @ kh / 8.0, dim=-1)                     # [2, 8, L, L]
     want = (vh @ a.transpose(2, 3)).reshape(2, 512, L)
     assert (o.double().cpu() - want).abs().max().item() < 2e-5
 
 
-def test_attention_kernel_with_several_utterances_and_their_own_key_counts():
+@pytest.mark.parametrize("split", [False, True])
+def test_attention_kernel_with_several_utterances_and_their_own_key_counts(split):
     """Three utterances of 150, 97 and 33 real frames in one launch at L = 150: every query of an utterance sees only that
     utterance's keys (fp64 softmax over the first keys[u] frames); what lies past them in q, k, v is large on purpose, so a
     key that leaks would show.  Outputs of the padding queries only have to be finite."""
@@ -249,7 +256,7 @@ def test_attention_kernel_with_several_utterances_and_their_own_key_counts():
     for u, n in enumerate(keys):
         k[2 * u:2 * u + 2, :, n:] *= 5.0
         v[2 * u:2 * u + 2, :, n:] += 100.0
-    o, _ = attention_op(q.cuda(), k.cuda(), v.cuda(), keys=keys)
+    o, _ = attention_op(q.cuda(), k.cuda(), v.cuda(), keys=keys, split=split)
     assert torch.isfinite(o).all()
     for u, n in enumerate(keys):
         r = slice(2 * u, 2 * u + 2)
@@ -259,10 +266,10 @@ def test_attention_kernel_with_several_utterances_and_their_own_key_counts():
         assert (o[r, :, :n].double().cpu() - want).abs().max().item() < 2e-5
 
 
-@pytest.fixture(scope="module")
-def cfm4(sd):
+@pytest.fixture(scope="module", **_FORMS)
+def cfm4(sd, request):
     from chatterbox_vllm_amd.cfm_decoder import CausalConditionalCFM
-    m = CausalConditionalCFM(sd, max_frames=300, generator=torch.Generator().manual_seed(3), max_batch=4)
+    m = CausalConditionalCFM(sd, max_frames=300, generator=torch.Generator().manual_seed(3), max_batch=4, split_bf16=request.param)
     yield m
     m.shutdown()
 

@@ -13,8 +13,9 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--frames", type=int, nargs="+", default=[1000])
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--iters", type=int, default=3)
+ap.add_argument("--split-bf16", action="store_true", help="attention launches on split-bf16 operands")
 args = ap.parse_args()
-m = CausalConditionalCFM(CW.synthetic_state_dict(), max_frames=max(args.frames))
+m = CausalConditionalCFM(CW.synthetic_state_dict(), max_frames=max(args.frames), split_bf16=args.split_bf16)
 for L in args.frames:
     inp = {k: v.cuda() for k, v in CW.synthetic_inputs(L, L // 3).items()}
     ts = CW.t_span(args.steps)

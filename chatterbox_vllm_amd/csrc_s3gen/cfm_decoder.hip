@@ -413,6 +413,34 @@ __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void lin_kernel(
             else if constexpr (OUT_ACT == OUT_SWISH) v[e] = v[e] * (1.0f / (1.0f + expf(-v[e])));
             else if constexpr (OUT_ACT == OUT_LRELU) v[e] = v[e] > 0.f ? v[e] : v[e] * 0.01f;
         }
+        if (a.qp) {
+            // four consecutive channels of q, k or v of one head at frame n, into attention operand order (cfm_split.h)
+            const int part = co0 >> 9, hh = (co0 & 511) >> 6, d = co0 & 63;
+            const size_t plane = (size_t)(a.p_ld / 32) * 2048, bh = ((size_t)z * kHeads + hh) * 3;
+            if (part < 2) {
+                unsigned short* const dst = (part == 0 ? a.qp : a.kp) + bh * plane + split_qk_offset(n, d);
+                const float sc = part == 0 ? a.q_scale : 1.0f;
+                unsigned lo[3], hi[3];
+                split_pair(v[0] * sc, v[1] * sc, lo[0], lo[1], lo[2]);
+                split_pair(v[2] * sc, v[3] * sc, hi[0], hi[1], hi[2]);
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<uint2*>(dst + pl * plane) = uint2{lo[pl], hi[pl]};
+            } else {
+                unsigned short* const dst = a.vp + bh * plane;
+#pragma unroll
+                for (int e = 0; e < 4; e += 2) {
+                    unsigned pp[3];
+                    split_pair(v[e], v[e + 1], pp[0], pp[1], pp[2]);
+                    const size_t o0 = split_v_offset(n, d + e), o1 = split_v_offset(n, d + e + 1);
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) {
+                        dst[pl * plane + o0] = (unsigned short)(pp[pl] & 0xffffu);
+                        dst[pl * plane + o1] = (unsigned short)(pp[pl] >> 16);
+                    }
+                }
+            }
+            return;
+        }
         if (a.yt && co0 >= a.yt_from) {
             *reinterpret_cast<f32x4*>(a.yt + z * a.yt_bs + (size_t)n * a.yt_ld + (co0 - a.yt_from)) = f32x4{v[0], v[1], v[2], v[3]};
             return;
@@ -693,7 +721,7 @@ int launch_attn(const AttnArgs& a, hipStream_t st) {
 
 // y[row][Cout][L] = out_act(conv(x[row][Cin][L])) (+ res) on both rows; pad = zero frames on the left.  y must not be x.
 int run_lin(const s3cfm* h, const Lin& l, const float* x, int x_rows, float* y, int y_rows, int L, int pad, int out_act, const float* res,
-            hipStream_t st, float* yt = nullptr, int yt_from = 0, const float* rsum = nullptr) {
+            hipStream_t st, float* yt = nullptr, int yt_from = 0, const float* rsum = nullptr, bool to_planes = false) {
     LinArgs a{};
     a.x = x; a.x_bs = (size_t)x_rows * h->ld; a.x_ld = h->ld;
     a.wt = l.wt; a.bias = l.bias;
@@ -702,6 +730,7 @@ int run_lin(const s3cfm* h, const Lin& l, const float* x, int x_rows, float* y, 
     a.yt = yt; a.yt_bs = (size_t)h->ld * kVtLd; a.yt_ld = kVtLd; a.yt_from = yt_from;
     a.Cin = l.Cin; a.Cout = l.Cout; a.CoutPad = (l.Cout + 31) / 32 * 32; a.K = l.K; a.pad = pad; a.L = L;
     a.rsum = rsum; a.ln_eps = 1e-5f;
+    if (to_planes) { a.qp = h->QP; a.kp = h->KP; a.vp = h->VP; a.p_ld = h->ld; a.q_scale = kQScale; }
     return launch_lin(a, out_act, h->rows, st);
 }
 
@@ -729,9 +758,8 @@ int run_resnet(s3cfm* h, const Resnet& r, const float* x, int x_rows, const floa
 int run_transformer(s3cfm* h, const Transformer& b, int L, hipStream_t st) {
     const int ld = h->ld;
     // norm1 rides in the q/k/v projection (LinArgs::rsum); q and k channel-major into QK, v frame-major into VT
-    if (run_lin(h, b.qkv, h->X, kC, h->QK, 2 * kInner, L, 0, OUT_NONE, nullptr, st, h->VT, 2 * kInner, b.qkv_rsum)) return 1;
+    if (run_lin(h, b.qkv, h->X, kC, h->QK, 2 * kInner, L, 0, OUT_NONE, nullptr, st, h->VT, 2 * kInner, b.qkv_rsum, h->split)) return 1;
     if (h->split) {
-        if (launch_split_qkv(h->QK, (size_t)2 * kInner * ld, h->VT, (size_t)ld * kVtLd, kVtLd, ld, h->rows, h->QP, h->KP, h->VP, st)) return 1;
         SplitAttnArgs sa{h->QP, h->KP, h->VP, h->O, (size_t)kInner * ld, ld, L, h->rows, {}};
         for (int u = 0; u < kMaxUtt; ++u) sa.Lk[u] = h->Lk[u];
         if (launch_attn_split(sa, st)) return 1;

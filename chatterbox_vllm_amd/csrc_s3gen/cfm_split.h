@@ -10,6 +10,22 @@
 
 constexpr int kSplitMaxUtt = 8;
 
+typedef __bf16 s3_bf16x2 __attribute__((ext_vector_type(2)));
+// (a, b) -> three dwords, each bf16 of a in the low half and of b in the high half: value, first and second remainder
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& p0, unsigned& p1, unsigned& p2) {
+    const s3_bf16x2 h0 = {(__bf16)a, (__bf16)b};
+    p0 = __builtin_bit_cast(unsigned, h0);
+    a -= __uint_as_float(p0 << 16);
+    b -= __uint_as_float(p0 & 0xffff0000u);
+    const s3_bf16x2 h1 = {(__bf16)a, (__bf16)b};
+    p1 = __builtin_bit_cast(unsigned, h1);
+    a -= __uint_as_float(p1 << 16);
+    b -= __uint_as_float(p1 & 0xffff0000u);
+    const s3_bf16x2 h2 = {(__bf16)a, (__bf16)b};
+    p2 = __builtin_bit_cast(unsigned, h2);
+}
+
+
 // Attention operands in the order the matrix instruction takes them, one 1 KiB block (64 lanes x 8 bf16) per load
 // instruction; element offsets inside the tensor of one (row, head, plane), which holds ld / 32 frame tiles of 2048 elements:
 //   Q and K: ((tile * 4 + s) * 64 + lane) * 8 + j   =  X[d = 16 s + 8 (lane / 32) + j][frame = 32 tile + lane % 32]
@@ -26,6 +42,16 @@ struct SplitAttnArgs {
     int Lk[kSplitMaxUtt];                   // keys of rows 2 u and 2 u + 1
 };
 int launch_attn_split(const SplitAttnArgs& a, hipStream_t st);
+
+// Element offsets of one value inside the tensor of its (row, head, plane), for the kernel that writes q, k, v straight into
+// operand order (lin_kernel's epilogue): frame n, channel d of the head
+__device__ __forceinline__ size_t split_qk_offset(int n, int d) {
+    return ((size_t)((n >> 5) * 4 + (d >> 4)) * 64 + ((d >> 3) & 1) * 32 + (n & 31)) * 8 + (d & 7);
+}
+__device__ __forceinline__ size_t split_v_offset(int n, int d) {
+    const int kk = n & 31;
+    return ((size_t)((n >> 5) * 4 + 2 * (kk >> 4) + (d >> 5)) * 64 + ((kk >> 2) & 1) * 32 + (d & 31)) * 8 + 4 * ((kk >> 3) & 1) + (kk & 3);
+}
 
 // fp32 q | k (channel-major [row][1024][ld]) and v (frame-major [row][ld][vt_ld]) -> the three operand tensors above
 int launch_split_qkv(const float* qk, size_t qk_bs, const float* vt, size_t vt_bs, int vt_ld, int ld, int rows, unsigned short* qp,

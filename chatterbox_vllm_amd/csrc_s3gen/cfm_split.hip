@@ -11,25 +11,11 @@
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kHeads = 8, kInner = 512;
 constexpr float kQScale = 0.125f * 1.44269504088896340736f;     // 1 / sqrt(64) and log2(e): softmax in base 2
 
-// (a, b) -> three dwords, each bf16 of a in the low half and of b in the high half: value, first and second remainder
-__device__ __forceinline__ void split_pair(float a, float b, unsigned& p0, unsigned& p1, unsigned& p2) {
-    const bf16x2 h0 = {(__bf16)a, (__bf16)b};
-    p0 = __builtin_bit_cast(unsigned, h0);
-    a -= __uint_as_float(p0 << 16);
-    b -= __uint_as_float(p0 & 0xffff0000u);
-    const bf16x2 h1 = {(__bf16)a, (__bf16)b};
-    p1 = __builtin_bit_cast(unsigned, h1);
-    a -= __uint_as_float(p1 << 16);
-    b -= __uint_as_float(p1 & 0xffff0000u);
-    const bf16x2 h2 = {(__bf16)a, (__bf16)b};
-    p2 = __builtin_bit_cast(unsigned, h2);
-}
 // eight values of one lane -> the lane's 16 bytes of each of the three operand planes
 __device__ __forceinline__ void split8(const float (&x)[8], u32x4& p0, u32x4& p1, u32x4& p2) {
 #pragma unroll
@@ -88,13 +74,6 @@ __global__ __launch_bounds__(256) void split_qkv_kernel(const float* __restrict_
     *reinterpret_cast<u32x4*>(vp + (bh + 2) * plane + blk) = p2;
 }
 
-#ifdef S3_SPLIT_TIMELINE
-__device__ long long g_tl[4096];
-#define TL_STAMP() do { __builtin_amdgcn_sched_barrier(0); if (blockIdx.x == 0 && threadIdx.x == 0 && tl_n < 4000) g_tl[tl_n++] = (long long)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define TL_STAMP() do { } while (0)
-#endif
-
 // both halves of a wave get the maximum (the sum) of a value over the two lanes n and n + 32: one lane-swap instruction
 __device__ __forceinline__ float half_max(float x) {
     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
@@ -152,22 +131,28 @@ __global__ __launch_bounds__(256) void attn_split_kernel(const unsigned short* _
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) Q[u][s][pl] = qb[pl * pl16 + (size_t)(tile * 4 + s) * 64];
     }
-    f32x16 o0[QT], o1[QT], sc[QT];
+    f32x16 o0[QT], o1[QT], sc[QT], sn[QT];
     float m[QT], l[QT];
 #pragma unroll
     for (int u = 0; u < QT; ++u) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { o0[u][i] = 0.f; o1[u][i] = 0.f; sc[u][i] = 0.f; }
+        for (int i = 0; i < 16; ++i) { o0[u][i] = 0.f; o1[u][i] = 0.f; sc[u][i] = 0.f; sn[u][i] = 0.f; }
         m[u] = -INFINITY;
         l[u] = 0.f;
     }
     const int ntiles = (Lk + 31) / 32;
     u32x4 K[4][3], V[4][3], P[QT][2][3];
-    auto load_k = [&](int t) {
+    auto load_k = [&](int tt) {
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) K[s][pl] = kb[pl * pl16 + (size_t)(t * 4 + s) * 64];
+            for (int pl = 0; pl < 3; ++pl) K[s][pl] = kb[pl * pl16 + (size_t)(tt * 4 + s) * 64];
+    };
+    auto load_v = [&](int tt) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) V[s][pl] = vb[pl * pl16 + (size_t)(tt * 4 + s) * 64];
     };
     // scores of the tile whose K is in registers: accumulator r of a lane is key 8 (r / 4) + 4 (lane / 32) + r % 4 of the
     // tile, query lane % 32; in units of ln 2 (the factor sits in Q)
@@ -181,16 +166,18 @@ __global__ __launch_bounds__(256) void attn_split_kernel(const unsigned short* _
 #pragma unroll
             for (int u = 0; u < QT; ++u) MFMA_SPLIT6(K[s], Q[u][s], dst[u]);
     };
-    // online softmax of query tile u on the scores in sc[u], then the probabilities as operand planes: accumulators
-    // 8 t2 .. 8 t2 + 7 of a lane are the eight keys of depth step t2 in the order V was written in
-    auto softmax = [&](int u) {
-        float mx = sc[u][0];
+    // online softmax of query tile u on the scores in s[u], then the probabilities as operand planes: accumulators
+    // 8 t2 .. 8 t2 + 7 of a lane are the eight keys of depth step t2 in the order V was written in.  No branch (the rescale
+    // of the output accumulators is unconditional), so that the whole of it can be scheduled among the matrix instructions
+    // of the next tile's scores.
+    auto softmax = [&](int u, f32x16 (&s)[QT]) {
+        float mx = s[u][0];
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[u][r]);
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[u][r]);
         const float m_new = fmaxf(m[u], half_max(mx));         // finite: every tile holds a key below Lk
         float ps = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { sc[u][r] = __builtin_amdgcn_exp2f(sc[u][r] - m_new); ps += sc[u][r]; }
+        for (int r = 0; r < 16; ++r) { s[u][r] = __builtin_amdgcn_exp2f(s[u][r] - m_new); ps += s[u][r]; }
         const float alpha = __builtin_amdgcn_exp2f(m[u] - m_new);
         l[u] = l[u] * alpha + half_sum(ps);
 #pragma unroll
@@ -201,25 +188,11 @@ __global__ __launch_bounds__(256) void attn_split_kernel(const unsigned short* _
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 unsigned a, bb, c;
-                split_pair(sc[u][8 * t2 + 2 * q], sc[u][8 * t2 + 2 * q + 1], a, bb, c);
+                split_pair(s[u][8 * t2 + 2 * q], s[u][8 * t2 + 2 * q + 1], a, bb, c);
                 P[u][t2][0][q] = a; P[u][t2][1][q] = bb; P[u][t2][2][q] = c;
             }
     };
-    int t = w;
-#ifdef S3_SPLIT_TIMELINE
-    int tl_n = 0;
-#endif
-    // V of a tile is requested a whole iteration before the second product that takes it (two buffers, the loop unrolled by
-    // two so that they swap without moves): with one buffer the request could only go out after the previous second product,
-    // one softmax block (1 900 cycles) ahead of its use, and the second product then waited 1 500 cycles for it.
-    u32x4 V2[4][3];
-    auto load_v = [&](u32x4 (&dst)[4][3], int tt) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) dst[s][pl] = vb[pl * pl16 + (size_t)(tt * 4 + s) * 64];
-    };
-    auto second_product = [&](const u32x4 (&Vt)[4][3]) {
+    auto second_product = [&]() {
         // consecutive matrix instructions go to different accumulators
         constexpr int ta[6] = {0, 2, 1, 0, 1, 0}, tb[6] = {2, 0, 1, 1, 0, 0};
 #pragma unroll
@@ -228,48 +201,31 @@ __global__ __launch_bounds__(256) void attn_split_kernel(const unsigned short* _
             for (int k = 0; k < 6; ++k)
 #pragma unroll
                 for (int u = 0; u < QT; ++u) {
-                    o0[u] = MFMA_BF16(Vt[2 * t2][ta[k]], P[u][t2][tb[k]], o0[u]);
-                    o1[u] = MFMA_BF16(Vt[2 * t2 + 1][ta[k]], P[u][t2][tb[k]], o1[u]);
+                    o0[u] = MFMA_BF16(V[2 * t2][ta[k]], P[u][t2][tb[k]], o0[u]);
+                    o1[u] = MFMA_BF16(V[2 * t2 + 1][ta[k]], P[u][t2][tb[k]], o1[u]);
                 }
     };
-    // one pipelined step: scores of tile t + 4 under the softmax of tile t, then the second product of tile t from Vc while
-    // Vn receives tile t + 4
-    auto step = [&](const u32x4 (&Vc)[4][3], u32x4 (&Vn)[4][3]) {
-        __builtin_amdgcn_sched_barrier(0);
-        TL_STAMP();
-        load_v(Vn, t + 4);
-        __builtin_amdgcn_sched_barrier(0);
-        f32x16 sn[QT];
-        scores(sn);
-#pragma unroll
-        for (int u = 0; u < QT; ++u) softmax(u);
-        __builtin_amdgcn_sched_barrier(0);
-        TL_STAMP();
-        load_k(t + 8 < ntiles ? t + 8 : t + 4);                // a wave's last tile loads itself again: no branch
-        __builtin_amdgcn_sched_barrier(0);
-        second_product(Vc);
-        __builtin_amdgcn_sched_barrier(0);
-        TL_STAMP();
-#pragma unroll
-        for (int u = 0; u < QT; ++u) sc[u] = sn[u];
-    };
+    int t = w;
     if (t < ntiles) {
         load_k(t);
-        load_v(V, t);
+        load_v(t);
         scores(sc);
         __builtin_amdgcn_sched_barrier(0);
         if (t + 4 < ntiles) load_k(t + 4);
-        bool in_v2 = false;                                    // which buffer holds V of tile t
-        for (; t + 8 < ntiles; t += 8) {
-            step(V, V2);
-            t += 4;
-            step(V2, V);
-            t -= 4;
-        }
-        if (t + 4 < ntiles) {
-            step(V, V2);
-            t += 4;
-            in_v2 = true;
+        for (; t + 4 < ntiles; t += 4) {
+            // the scores of tile t + 4 are issued in the same basic block as the softmax of tile t
+            __builtin_amdgcn_sched_barrier(0);
+            scores(sn);
+#pragma unroll
+            for (int u = 0; u < QT; ++u) softmax(u, sc);
+            __builtin_amdgcn_sched_barrier(0);
+            load_k(t + 8 < ntiles ? t + 8 : t + 4);            // a wave's last tile loads itself again: no branch
+            __builtin_amdgcn_sched_barrier(0);
+            second_product();
+            __builtin_amdgcn_sched_barrier(0);
+            load_v(t + 4);
+#pragma unroll
+            for (int u = 0; u < QT; ++u) sc[u] = sn[u];
         }
         // the wave's last tile: the only one that can hold keys past Lk
         const int key0 = t * 32;
@@ -281,9 +237,8 @@ __global__ __launch_bounds__(256) void attn_split_kernel(const unsigned short* _
                     if (key0 + 8 * (r >> 2) + 4 * half + (r & 3) >= Lk) sc[u][r] = -INFINITY;
         }
 #pragma unroll
-        for (int u = 0; u < QT; ++u) softmax(u);
-        if (in_v2) second_product(V2);
-        else second_product(V);
+        for (int u = 0; u < QT; ++u) softmax(u, sc);
+        second_product();
     }
     // merge the four waves' partial results, one query tile at a time through the same 32 KiB
 #pragma unroll
@@ -374,13 +329,6 @@ int time_launches(int iters, hipStream_t st, float* avg_us, const std::function<
     return rc;
 }
 }  // namespace
-
-#ifdef S3_SPLIT_TIMELINE
-extern "C" int s3cfm_read_timeline(long long* out, int32_t n) {
-    S3_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tl), (size_t)n * sizeof(long long)));
-    return 0;
-}
-#endif
 
 extern "C" int s3cfm_op_attention_split(const float* qk_dev, const float* vt_dev, int32_t n_utt, const int32_t* keys, int32_t L, int32_t ld,
                                         float* o_dev, int32_t iters, float* attn_avg_us, float* split_avg_us, void* stream) {

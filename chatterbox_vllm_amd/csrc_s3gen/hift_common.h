@@ -86,6 +86,9 @@ struct LinArgs {
     float* yt; size_t yt_bs; int yt_ld, yt_from;   // yt not null: channels >= yt_from go to yt[z][n][co - yt_from] (frame-major)
     int Cin, Cout, CoutPad, K, pad, L;
     const float* rsum; float ln_eps;         // rsum not null: LayerNorm of the input folded into this layer
+    // qp not null (a q | k | v projection of 3 x 512 channels, 8 heads x 64): nothing goes to y / yt; the outputs are written
+    // as split-bf16 attention operands instead (cfm_split.h: q scaled by q_scale, three planes each), p_ld = their row stride
+    unsigned short *qp, *kp, *vp; int p_ld; float q_scale;
 };
 enum { OUT_NONE = 0, OUT_GELU = 1, OUT_SWISH = 2, OUT_LRELU = 3 };   // OUT_LRELU: slope 0.01
 int launch_lin(const LinArgs& a, int out_act, int rows, hipStream_t st);

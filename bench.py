@@ -352,6 +352,19 @@ def flow_decoder_leg(device, frames=1000, n_timesteps=10, iters=3, per_call=8):
     e1.record()
     torch.cuda.synchronize(device)
     ev8_ms = e0.elapsed_time(e1)
+    # the same solve with the attention launches on split-bf16 operands (s3cfm_set_split_bf16): a labelled extra, the fp32
+    # matrix instruction stays the leg's value; its distance from the fp32 form's result is reported with it
+    ref32 = m.solve_euler(inp["noise"], ts, inp["mu"], inp["spks"], inp["cond"])
+    m.set_split_bf16(True)
+    got_split = m.solve_euler(inp["noise"], ts, inp["mu"], inp["spks"], inp["cond"])
+    torch.cuda.synchronize(device)
+    e0.record()
+    for _ in range(iters):
+        m.solve_euler(inp["noise"], ts, inp["mu"], inp["spks"], inp["cond"])
+    e1.record()
+    torch.cuda.synchronize(device)
+    split_ms = e0.elapsed_time(e1) / iters
+    split_diff = ((got_split - ref32).abs().max() / ref32.abs().max()).item()
     m.shutdown()
     flop = CW.estimator_flop(frames) * n_timesteps
     achieved = flop / (ev_ms * 1e-3) / 1e12
@@ -365,6 +378,11 @@ def flow_decoder_leg(device, frames=1000, n_timesteps=10, iters=3, per_call=8):
     rec["several_per_call"] = {"utterances_per_call": per_call, "value": round(per_call * frames * 0.02 / (ev8_ms * 1e-3), 1),
                                "event_ms_per_call": round(ev8_ms, 3), "achieved": round(per_call * flop / (ev8_ms * 1e-3) / 1e12, 2),
                                "frac": round(per_call * flop / (ev8_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)}
+    rec["split_bf16_attention"] = {"value": round(frames * 0.02 / (split_ms * 1e-3), 1), "event_ms_per_call": round(split_ms, 3),
+                                   "max_difference_from_the_fp32_form": float(f"{split_diff:.2e}"),
+                                   "note": "attention operands as three bf16 values each, six partial products per product on the bf16 "
+                                           "matrix instruction, fp32 accumulation; held to the fp32 form's tolerances against fp64 "
+                                           "(tests/test_cfm_gpu.py runs every decoder test in both forms); off by default"}
     from oracle import cfm_oracle as CO
     small = frames
     inp_c = CW.synthetic_inputs(small, small // 3)
@@ -417,7 +435,7 @@ def token_to_waveform_leg(device, prompt_tokens=250, new_tokens=250, iters=3):
             "parity": "encoder, flow decoder and vocoder pinned by reference outputs (flow decoder: the inside of three diffusers classes unpinned)"}
 
 
-def s3gen_job_leg(device, lengths, prompt_tokens=250, variants=((2, 4), (1, 1), (1, 8), (3, 4))):
+def s3gen_job_leg(device, lengths, prompt_tokens=250, variants=((2, 4), (1, 1), (1, 8), (3, 4), (2, 4, True))):
     """The second half of the reference's benchmark.py for the same job: every chunk's speech tokens through the token ->
     waveform chain with a 10 s voice prompt.  The token counts are the ones the T3 leg generated for the job's chunks; the
     token values and all weights are seeded synthetic.  `variants` are (copies of the chain in flight, utterances per
@@ -425,7 +443,8 @@ def s3gen_job_leg(device, lengths, prompt_tokens=250, variants=((2, 4), (1, 1), 
     launches, several copies (each with its own weights, workspace, stream and host thread) use the CUs that one copy's
     launches leave idle; chunks are handed out longest first.  `value` is the FIRST variant, (2, 4): the schedule the
     facade builds by default (ChatterboxTTS.from_local / from_synthetic).  (1, 1) is one utterance at a time, as the
-    reference runs it (tts.py:428-557).  Reported beside the T3 time so that the whole text -> waveform job has a number
+    reference runs it (tts.py:428-557).  A third entry True repeats a schedule with the flow-matching decoder's attention
+    on split-bf16 operands (off by default; reported as `split_bf16_attention`, never as `value`).  Reported beside the T3 time so that the whole text -> waveform job has a number
     (the reference's README reports the two times for its run, README.md:150-153)."""
     from chatterbox_vllm_amd import cfm_weights as CW, flow_weights as FW, hift_weights as HW
     from chatterbox_vllm_amd.s3gen import S3Token2Wav
@@ -441,8 +460,10 @@ def s3gen_job_leg(device, lengths, prompt_tokens=250, variants=((2, 4), (1, 1), 
     toks = [torch.randint(0, 6561, (n,), generator=g).to(dev) for n in lengths]
     longest = sorted(range(len(toks)), key=lambda i: -lengths[i])
     runs = []
-    for nw, nb in variants:
-        s3 = S3Token2Wav(flow_sd, hift_sd, max_tokens=prompt_tokens + max(lengths), device=device, max_batch=nb, chains=nw)
+    for var in variants:
+        nw, nb, split = var[0], var[1], len(var) > 2 and bool(var[2])
+        s3 = S3Token2Wav(flow_sd, hift_sd, max_tokens=prompt_tokens + max(lengths), device=device, max_batch=nb, chains=nw,
+                         split_bf16=split)
         s3.render_many([toks[i] for i in longest[:2 * nw * nb]], ref)          # warm-up of every copy
         torch.cuda.synchronize(device)
         t0 = time.perf_counter()
@@ -452,7 +473,7 @@ def s3gen_job_leg(device, lengths, prompt_tokens=250, variants=((2, 4), (1, 1), 
         samples = sum(w.shape[1] for w in wavs)
         s3.shutdown()
         runs.append({"utterances_in_flight": nw, "utterances_per_call": nb, "seconds": round(dt, 3),
-                     "value": round(samples / 24000 / dt, 1), "audio_seconds": round(samples / 24000, 1)})
+                     "value": round(samples / 24000 / dt, 1), "audio_seconds": round(samples / 24000, 1), "split": split})
     first = runs[0]
     rec = {"workload": f"S3Gen over the job's {len(lengths)} chunks ({sum(lengths)} speech tokens, {min(lengths)}-{max(lengths)} per chunk), "
                        f"{prompt_tokens}-token voice prompt, 10 Euler steps, seeded synthetic weights",
@@ -460,8 +481,13 @@ def s3gen_job_leg(device, lengths, prompt_tokens=250, variants=((2, 4), (1, 1), 
            "schedule": "the facade's default: two copies of the chain, four utterances per call, longest first",
            "utterances_in_flight": first["utterances_in_flight"], "utterances_per_call": first["utterances_per_call"],
            "seconds": first["seconds"], "audio_seconds": first["audio_seconds"], "dtype": "f32"}
-    rec["variants"] = [{k: v for k, v in r.items() if k != "audio_seconds"} for r in runs[1:]]
-    rec["one_utterance_at_a_time_seconds"] = next((r["seconds"] for r in runs if (r["utterances_in_flight"], r["utterances_per_call"]) == (1, 1)), None)
+    rec["variants"] = [{k: v for k, v in r.items() if k not in ("audio_seconds", "split")} for r in runs[1:] if not r["split"]]
+    sp = next((r for r in runs if r["split"]), None)
+    if sp:
+        rec["split_bf16_attention"] = {"utterances_in_flight": sp["utterances_in_flight"], "utterances_per_call": sp["utterances_per_call"],
+                                       "seconds": sp["seconds"], "value": sp["value"]}
+    rec["one_utterance_at_a_time_seconds"] = next((r["seconds"] for r in runs if (r["utterances_in_flight"], r["utterances_per_call"]) == (1, 1)
+                                                   and not r["split"]), None)
     return rec
 
 

@@ -36,12 +36,14 @@ S3GEN_SR = 24000
 class S3Token2Wav:
     def __init__(self, flow_state_dict: Dict[str, torch.Tensor], mel2wav_state_dict: Dict[str, torch.Tensor],
                  decoder: Optional[Callable] = None, max_tokens: int = 1500, device: int = 0, max_batch: int = 1,
-                 chains: int = 1):
+                 chains: int = 1, split_bf16: bool = False):
         self.device = torch.device("cuda", device)
         self.encoder = FlowEncoder(flow_state_dict, max_tokens=max_tokens, device=device)
         self.mel2wav = HiFTGenerator(mel2wav_state_dict, max_batch=1, max_frames=2 * max_tokens, device=device)
         self._own_decoder = decoder is None
-        self.decoder = (CausalConditionalCFM(flow_state_dict, max_frames=2 * max_tokens, device=device, max_batch=max_batch)
+        # split_bf16: the decoder's attention launches on bf16 triples (CausalConditionalCFM; off = the fp32 matrix instruction)
+        self.decoder = (CausalConditionalCFM(flow_state_dict, max_frames=2 * max_tokens, device=device, max_batch=max_batch,
+                                             split_bf16=split_bf16)
                         if decoder is None else decoder)
         self.max_batch = max_batch
         # silence the first 20 ms and fade in over the next 20 ms (s3gen.py:247-251)
@@ -53,7 +55,7 @@ class S3Token2Wav:
         self.siblings: List["S3Token2Wav"] = []
         if chains > 1 and decoder is None:
             for _ in range(chains - 1):
-                sib = S3Token2Wav(flow_state_dict, mel2wav_state_dict, None, max_tokens, device, max_batch, 1)
+                sib = S3Token2Wav(flow_state_dict, mel2wav_state_dict, None, max_tokens, device, max_batch, 1, split_bf16)
                 sib.decoder.rand_noise = self.decoder.rand_noise
                 self.siblings.append(sib)
         self._streams = [torch.cuda.Stream(device=self.device) for _ in self.siblings]

@@ -180,7 +180,8 @@ class ChatterboxTTS:
             s3_sd = load_file(str(ckpt_dir / "s3gen.safetensors"))
             kwargs["s3gen"] = S3Token2Wav({k[len("flow."):]: v for k, v in s3_sd.items() if k.startswith("flow.")},
                                           {k[len("mel2wav."):]: v for k, v in s3_sd.items() if k.startswith("mel2wav.")},
-                                          max_batch=min(4, max(1, max_batch_size)), chains=2)
+                                          max_batch=min(4, max(1, max_batch_size)), chains=2,
+                                          split_bf16=_env_flag("CHATTERBOX_S3GEN_SPLIT_BF16"))
         cfg = cls.variant_config(variant)
         # the backbone's depth is the checkpoint's (30 for the published ones): a cut-down checkpoint loads as what it is
         depth = 1 + max((int(k.split(".")[2]) for k in sd if k.startswith("tfmr.layers.")), default=-1)
@@ -219,7 +220,8 @@ class ChatterboxTTS:
             flow_sd = dict(flow_weights.synthetic_state_dict())
             flow_sd.update(cfm_weights.synthetic_state_dict())
             kwargs["s3gen"] = S3Token2Wav(flow_sd, hift_weights.synthetic_state_dict(), max_tokens=kwargs.get("max_model_len", 1000) + 256,
-                                          max_batch=min(4, max(1, kwargs.get("max_batch_size", 10))), chains=2)
+                                          max_batch=min(4, max(1, kwargs.get("max_batch_size", 10))), chains=2,
+                                          split_bf16=_env_flag("CHATTERBOX_S3GEN_SPLIT_BF16"))
         cfg = cls.variant_config(variant)
         if n_layers is not None:
             cfg = T3ModelConfig(n_layers=n_layers, text_vocab=cfg.text_vocab)

@@ -123,17 +123,20 @@ def test_limits(cfm):
         cfm.solve_euler(inp["noise"], CW.t_span(2), inp["mu"], inp["spks"], inp["cond"])
 
 
-def test_token_to_waveform_chain_with_the_packaged_decoder(sd):
+@pytest.mark.parametrize("split", [False, True], ids=["fp32", "split_bf16"])
+def test_token_to_waveform_chain_with_the_packaged_decoder(sd, split):
     """S3Token2Wav with its default decoder: tokens -> mu (FlowEncoder) -> mel (CausalConditionalCFM) -> waveform
     (HiFTGenerator).  The mel is held to the two restatements chained in fp64 (flow.py:262-291 with finalize=True); the
-    waveform is the vocoder's own for that mel."""
+    waveform is the vocoder's own for that mel.  Both arithmetic forms of the decoder's attention, through the chain's own
+    switch."""
     from chatterbox_vllm_amd import flow_weights as FW, hift_weights as HW
     from chatterbox_vllm_amd.s3gen import S3Token2Wav
     from oracle import cfm_oracle as O, flow_encoder_oracle as FO
     flow_sd = dict(FW.synthetic_state_dict())
     flow_sd.update(sd)
     torch.manual_seed(11)                                    # the decoder draws its fixed noise at construction
-    s3 = S3Token2Wav(flow_sd, HW.synthetic_state_dict(), max_tokens=64)
+    s3 = S3Token2Wav(flow_sd, HW.synthetic_state_dict(), max_tokens=64, split_bf16=split)
+    assert s3.decoder.split_bf16 == split
     n_prompt, n_new = 14, 30
     g = torch.Generator().manual_seed(8)
     ref = {"prompt_token": FW.synthetic_tokens(n_prompt, seed=3).view(1, -1),

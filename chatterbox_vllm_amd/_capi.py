@@ -80,6 +80,7 @@ SIGNATURES = {
     "t3_engine_add_request": ([_P, C.c_int64, _I32P, C.c_int32, C.POINTER(C.c_float), C.POINTER(T3Sampling)], C.c_int),
     "t3_engine_step": ([_P, C.POINTER(C.c_int64), _I32P, _I32P, C.c_int32, _I32P], C.c_int),
     "t3_engine_set_schedule_policy": ([_P, C.c_int32], C.c_int),
+    "t3_engine_set_prefill_chunk": ([_P, C.c_int32], C.c_int),
     "t3_engine_abort": ([_P, C.c_int64], C.c_int),
     "t3_engine_has_unfinished": ([_P], C.c_int),
     "t3_engine_get_stats": ([_P, C.POINTER(T3StepStats)], C.c_int),

@@ -395,12 +395,20 @@ int launch_attn_decode_oproj(const bf16_t* qkv, int ldq, float* slab, int rows, 
 // ------------------------------------------------------------------------------------
 #define PF_LD 72   // LDS row stride in elements (64 + 8 pad: 144 B keeps 16-B alignment, spreads banks)
 
+// Chunked prompts (POOL): a sequence's rows cover positions seq_first[seq] .. only, the rest of its prompt went through an
+// earlier launch.  Every key is then read from the KV pool through the sequence's block-table row (this launch's own keys
+// were written there by the QKV projection before it): the same bf16 values in the same tiles, so a prompt's bits do not
+// depend on how it is cut.
+template <bool POOL>
 __global__ __launch_bounds__(256) void attn_prefill_kernel(const bf16_t* __restrict__ qkv, int ldq,
                                                            bf16_t* __restrict__ out, int ldo,
                                                            const int32_t* __restrict__ seq_start,
                                                            const int32_t* __restrict__ tiles, int H,
                                                            const int32_t* __restrict__ seq_pfx, int npfx,
-                                                           const bf16_t* __restrict__ pool_layer) {
+                                                           const bf16_t* __restrict__ pool_layer,
+                                                           const int32_t* __restrict__ seq_first,
+                                                           const int32_t* __restrict__ seq_stream,
+                                                           const int32_t* __restrict__ block_table, int max_pages) {
     __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * PF_LD];
     __shared__ __attribute__((aligned(16))) bf16_t Vt[64 * PF_LD];
     const int hd = 64, D = H * hd;
@@ -408,7 +416,8 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const bf16_t* __restr
     const int h = blockIdx.y;
     // positions: the sequence's rows are positions base .. P-1; q0, qrow, key indices are positions
     const int pfx = seq_pfx ? seq_pfx[seq] : -1;
-    const int base = pfx >= 0 ? npfx : 0;
+    const int base = POOL ? seq_first[seq] : (pfx >= 0 ? npfx : 0);
+    const int32_t* const bt = POOL ? block_table + (size_t)seq_stream[seq] * max_pages : nullptr;
     const int s0 = seq_start[seq] - base, P = seq_start[seq + 1] - s0;     // row of position p = s0 + p
     const int q0 = base + tiles[2 * blockIdx.x + 1];
     const bf16_t* pk = pool_layer + ((size_t)(pfx >= 0 ? pfx : 0) * 2 * H + h) * (T3_PAGE * 64);   // prefix K slab of this head
@@ -439,10 +448,16 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const bf16_t* __restr
             const int idx = tid + 256 * i, key = idx >> 3, ch = idx & 7;
             int gk = kt * 64 + key;
             gk = gk < P ? gk : P - 1;
-            const bool in_pfx = gk < base;
-            const bf16_t* kp = in_pfx ? pk + gk * 64 + ch * 8 : qkv + (size_t)(s0 + gk) * ldq + D + h * hd + ch * 8;
+            const bool in_pfx = pfx >= 0 && gk < npfx;
+            const bf16_t* kp;
+            if constexpr (POOL) {
+                kp = in_pfx ? pk + gk * 64 + ch * 8
+                            : pool_layer + ((size_t)bt[gk >> 6] * 2 * H + h) * (T3_PAGE * 64) + (gk & 63) * 64 + ch * 8;
+            } else {
+                kp = in_pfx ? pk + gk * 64 + ch * 8 : qkv + (size_t)(s0 + gk) * ldq + D + h * hd + ch * 8;
+            }
             const u32x4 kv = *reinterpret_cast<const u32x4*>(kp);
-            const u32x4 vv = *reinterpret_cast<const u32x4*>(kp + (in_pfx ? (size_t)H * (T3_PAGE * 64) : (size_t)D));
+            const u32x4 vv = *reinterpret_cast<const u32x4*>(kp + ((POOL || in_pfx) ? (size_t)H * (T3_PAGE * 64) : (size_t)D));
             *reinterpret_cast<u32x4*>(&Ks[key * PF_LD + ch * 8]) = kv;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -526,13 +541,21 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const bf16_t* __restr
 
 int launch_attn_prefill(const bf16_t* qkv, int ldq, bf16_t* out, const int32_t* seq_start_dev,
                         const int32_t* tiles_dev, int ntiles, int H, int hd, hipStream_t st,
-                        const int32_t* seq_pfx_dev, int npfx, const KvView* kv, int layer) {
+                        const int32_t* seq_pfx_dev, int npfx, const KvView* kv, int layer,
+                        const int32_t* seq_first_dev, const int32_t* seq_stream_dev) {
     T3_REQUIRE(hd == 64 && ntiles >= 1, "attn_prefill: head_dim must be 64");
     T3_REQUIRE(seq_pfx_dev == nullptr || (kv && kv->H == H && kv->hd == hd && npfx >= 1 && npfx <= T3_PAGE),
                "attn_prefill: a shared prefix needs the KV pool and must fit one page");
-    const bf16_t* pool_layer = seq_pfx_dev ? kv->pool + (size_t)layer * kv->layer_stride : nullptr;
-    T3_LAUNCH(attn_prefill_kernel, dim3(ntiles, H), dim3(256), 0, st, qkv, ldq, out, H * hd, seq_start_dev,
-                       tiles_dev, H, seq_pfx_dev, npfx, pool_layer);
+    T3_REQUIRE(!seq_first_dev == !seq_stream_dev && (!seq_first_dev || (kv && kv->H == H && kv->hd == hd && kv->block_table)),
+               "attn_prefill: chunked prompts need first positions, streams and the KV pool");
+    const bf16_t* pool_layer = (seq_pfx_dev || seq_first_dev) ? kv->pool + (size_t)layer * kv->layer_stride : nullptr;
+    if (seq_first_dev)
+        T3_LAUNCH(attn_prefill_kernel<true>, dim3(ntiles, H), dim3(256), 0, st, qkv, ldq, out, H * hd, seq_start_dev, tiles_dev, H,
+                  seq_pfx_dev, npfx, pool_layer, seq_first_dev, seq_stream_dev, kv->block_table, kv->max_pages);
+    else
+    T3_LAUNCH(attn_prefill_kernel<false>, dim3(ntiles, H), dim3(256), 0, st, qkv, ldq, out, H * hd, seq_start_dev,
+                       tiles_dev, H, seq_pfx_dev, npfx, pool_layer, static_cast<const int32_t*>(nullptr),
+                       static_cast<const int32_t*>(nullptr), static_cast<const int32_t*>(nullptr), 0);
     T3_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -90,6 +90,8 @@ struct Request {
     bool aborted = false;
     bool poisoned = false;            // ended on non-finite logits: its KV pages hold NaN and are cleared before reuse
     bool prefilling = false;          // admitted into a prefill job that has not been reported yet
+    int pf_pos = 0;                   // next position of the prompt that has not gone through the layers (chunked prompts)
+    int chunks_out = 0;               // launched, unreported jobs that carry a chunk of its prompt without finishing it
     int voice = -1;                   // shared-prefix entry this request reads positions 0..33 from
     bool builds_voice = false;        // its prefill step also carries the voice's 34 rows
 };
@@ -150,7 +152,7 @@ struct t3_engine {
     hipStream_t cur = nullptr;                          // the stream the phase being enqueued uses
     hipEvent_t fork_ev[2] = {nullptr, nullptr};
     // the prefill job that has been launched on the prefill stream and not yet reported
-    struct PrefillJob { bool valid = false; int parity = 0; std::vector<Request*> reqs; } pjob;
+    struct PrefillJob { bool valid = false; int parity = 0; std::vector<Request*> reqs, partial; } pjob;   // partial: chunk carried, prompt not finished
     hipEvent_t pjob_done = nullptr;
     bool overlap_prefill = true;
     bool fused_norm = true;                             // few-row decode steps: norm inside the QKV / gate_up projections
@@ -219,7 +221,7 @@ struct t3_engine {
         Pinned<uint8_t> blk;
         int32_t* out_tokens_dev = nullptr;
         int32_t *row_stream, *row_pos, *row_ctx, *row_pfx, *ekind, *eidx, *eaux, *row_c, *row_u, *slot, *step, *a_rows,
-                *seq_start, *seq_pfx, *tiles, *prompt_ids, *out_tokens = nullptr;     // host views (out_tokens: its own pinned buffer)
+                *seq_start, *seq_pfx, *seq_first, *seq_stream, *tiles, *prompt_ids, *out_tokens = nullptr;   // host views (out_tokens: its own pinned buffer)
         float *rep, *temp, *top_p, *min_p;
         uint64_t* seed;
         size_t rows_cap = 0, req_cap = 0;
@@ -231,6 +233,7 @@ struct t3_engine {
         bool valid = false;
         int parity = 0;
         std::vector<Request*> admitted, running;
+        std::vector<Request*> partial;                  // prompts the step carried a chunk of without finishing them
     } inflight;
     int parity = 0;
     hipEvent_t step_done[2] = {nullptr, nullptr};
@@ -238,6 +241,7 @@ struct t3_engine {
 
     std::deque<std::unique_ptr<Request>> waiting;
     int schedule_policy = 0;                            // 0: first come first served; 1: longest prompt + max_tokens first; 2: longest prompt first
+    int prefill_chunk = 0;                              // > 0: positions a prefill job may carry; a prompt that does not fit is cut
     std::vector<std::unique_ptr<Request>> slots;
 
     std::unordered_map<int, hipGraphExec_t> graphs;
@@ -287,7 +291,7 @@ int meta_alloc(t3_engine::Meta& m, size_t rows, size_t reqs, size_t prompt_ids) 
     m.rows_cap = rows; m.req_cap = reqs;
     // sequences of a prefill step: up to two streams per request plus one per voice built in the step
     const size_t seqs = 3 * reqs + 2, tiles = rows / 32 + 5 * reqs + 64;
-    const size_t ni = rows * 7 + reqs * 5 + reqs * 2 /*a_rows*/ + 2 * seqs + 2 * tiles + prompt_ids + 64;
+    const size_t ni = rows * 7 + reqs * 5 + reqs * 2 /*a_rows*/ + 4 * seqs + 2 * tiles + prompt_ids + 64;
     const size_t nu = reqs + 4, nf = reqs * 4 + 16;
     if (m.blk.alloc(sizeof(uint64_t) * nu + sizeof(float) * nf + sizeof(int32_t) * ni)) return 1;
     m.seed = reinterpret_cast<uint64_t*>(m.blk.h);
@@ -300,7 +304,8 @@ int meta_alloc(t3_engine::Meta& m, size_t rows, size_t reqs, size_t prompt_ids) 
     m.row_stream = carve(p, rows); m.row_pos = carve(p, rows); m.row_ctx = carve(p, rows); m.row_pfx = carve(p, rows);
     m.ekind = carve(p, rows); m.eidx = carve(p, rows); m.eaux = carve(p, rows);
     m.row_c = carve(p, reqs); m.row_u = carve(p, reqs); m.slot = carve(p, reqs); m.step = carve(p, reqs);
-    m.a_rows = carve(p, 2 * reqs); m.seq_start = carve(p, seqs); m.seq_pfx = carve(p, seqs); m.tiles = carve(p, 2 * tiles);
+    m.a_rows = carve(p, 2 * reqs); m.seq_start = carve(p, seqs); m.seq_pfx = carve(p, seqs); m.seq_first = carve(p, seqs);
+    m.seq_stream = carve(p, seqs); m.tiles = carve(p, 2 * tiles);
     m.prompt_ids = carve(p, prompt_ids);
     m.rep = carve(f, reqs); m.temp = carve(f, reqs); m.top_p = carve(f, reqs); m.min_p = carve(f, reqs);
     return 0;
@@ -370,7 +375,7 @@ int dmalloc(bf16_t** p, size_t elems) { T3_HIP_CHECK(hipMalloc(reinterpret_cast<
 // d_emb_slot (decode steps of more than GEMM_FUSED_NORM_ROWS rows): the first norm fetches the rows' token embeddings itself
 int run_layers(t3_engine* e, int rows, const int32_t* d_pos, const int32_t* d_stream, const int32_t* d_ctx,
                bool prefill, const int32_t* d_seq_start, const int32_t* d_tiles, int ntiles, const int32_t* d_pfx,
-               const int32_t* d_emb_slot = nullptr) {
+               const int32_t* d_emb_slot = nullptr, const int32_t* d_seq_first = nullptr, const int32_t* d_seq_stream = nullptr) {
     const t3_config& c = e->cfg;
     const int D = c.d_model, F = c.d_ff, H = c.n_heads, hd = c.head_dim;
     hipStream_t st = e->cur;
@@ -415,7 +420,7 @@ int run_layers(t3_engine* e, int rows, const int32_t* d_pos, const int32_t* d_st
         T3_RUN(e, K_QKV, li, WB * 3 * D * D, prefill ? launch_gemm_prompt(EPI_QKV_ROPE, g, st) : launch_gemm(EPI_QKV_ROPE, g, st));
         if (prefill) {
             T3_RUN(e, K_ATTN_PREFILL, li, 2LL * rows * 4 * D, launch_attn_prefill(e->b->qkv, 3 * D, e->b->att, d_seq_start, d_tiles, ntiles, H, hd, st,
-                                                                                          d_pfx, kCondRows, &kv, li));
+                                                                                          d_pfx, kCondRows, &kv, li, d_seq_first, d_seq_stream));
         } else if (split_attn) {
             // a few rows: one single-wave workgroup per (head, row, wave), so that a row's K/V are pulled by eight CUs;
             // o_proj merges the wave states itself (same arithmetic, same bits as the one-workgroup form).  The merge in
@@ -580,13 +585,22 @@ int prefill_after_main(t3_engine* e) {
 }
 
 // ---- prefill of newly admitted requests ------------------------------------------------
-int run_prefill(t3_engine* e, const std::vector<Request*>& reqs) {
+// One (request, position range) of a prefill job.  Whole prompts: [first position, prompt_len).  Chunked prompts
+// (prefill_chunk > 0): a job carries at most prefill_chunk positions, so a prompt may take several jobs; the chunk that
+// ends at prompt_len samples the request's first token.
+struct PrefillPart { Request* r; int p0, p1; };
+
+// reqs_out: the requests whose prompt ends in this job, in the order of the sampler's rows
+int run_prefill(t3_engine* e, const std::vector<PrefillPart>& parts, std::vector<Request*>& reqs_out) {
     const t3_config& c = e->cfg;
     t3_engine::Meta& m = e->pm[e->parity];
-    const int S = e->rows_per_req, Q = e->kv_per_req, n = (int)reqs.size();
+    const int S = e->rows_per_req, Q = e->kv_per_req;
     const bool share = e->share_prefix;
-    const int first_pos = share ? kCondRows : 0;          // first position a request's own rows cover
+    const bool chunked = e->prefill_chunk > 0;
     int row = 0, nseq = 0, ntiles = 0, pid = 0;
+    reqs_out.clear();
+    for (const PrefillPart& pt : parts) if (pt.p1 == pt.r->prompt_len) reqs_out.push_back(pt.r);
+    const int n = (int)reqs_out.size();                   // requests that reach the sampler
     // the prompts run on the prefill stream, behind everything the main stream holds so far
     e->cur = e->pstream;
     e->b = &e->pbufs;
@@ -594,14 +608,14 @@ int run_prefill(t3_engine* e, const std::vector<Request*>& reqs) {
     // voices first met in this step: their 34 rows go through the layers as sequences of their own and
     // leave K/V in the voice page, which the requests' rows read in the same launches
     if (share)
-        for (int i = 0; i < n; ++i) {
-            Request& r = *reqs[i];
+        for (const PrefillPart& pt : parts) {
+            Request& r = *pt.r;
             if (!r.builds_voice) continue;
             r.builds_voice = false;
             const int v = r.voice;
             T3_HIP_CHECK(hipMemcpyAsync(e->cond_buf + (size_t)v * kCondRows * c.d_model, e->voices[v].cond.data(),
                                         sizeof(float) * kCondRows * c.d_model, hipMemcpyHostToDevice, e->cur));
-            m.seq_start[nseq] = row; m.seq_pfx[nseq] = -1;
+            m.seq_start[nseq] = row; m.seq_pfx[nseq] = -1; m.seq_first[nseq] = 0; m.seq_stream[nseq] = e->n_streams + v;
             m.tiles[2 * ntiles] = nseq; m.tiles[2 * ntiles + 1] = 0; ++ntiles;
             for (int p = 0; p < kCondRows; ++p, ++row) {
                 m.row_stream[row] = e->n_streams + v; m.row_pos[row] = p; m.row_ctx[row] = p + 1;
@@ -609,18 +623,22 @@ int run_prefill(t3_engine* e, const std::vector<Request*>& reqs) {
             }
             ++nseq;
         }
-    for (int i = 0; i < n; ++i) {
-        Request& r = *reqs[i];
+    int fin = 0;                                          // index among the finishing requests
+    for (const PrefillPart& pt : parts) {
+        Request& r = *pt.r;
         const int T = (int)r.text.size(), P = r.prompt_len;
-        if (grow_pages(e, r, P)) return 1;
-        if (!share)
+        const bool last = pt.p1 == P, first = pt.p0 == (share ? kCondRows : 0);
+        if (grow_pages(e, r, pt.p1)) return 1;
+        if (!share && first)
             T3_HIP_CHECK(hipMemcpyAsync(e->cond_buf + (size_t)r.slot * kCondRows * c.d_model, r.cond.data(),
                                         sizeof(float) * kCondRows * c.d_model, hipMemcpyHostToDevice, e->cur));
         for (int u = 0; u < Q; ++u) {
             m.seq_start[nseq] = row;
             m.seq_pfx[nseq] = share ? (int32_t)(e->n_pages + r.voice) : -1;
-            for (int q0 = 0; q0 < P - first_pos; q0 += 64) { m.tiles[2 * ntiles] = nseq; m.tiles[2 * ntiles + 1] = q0; ++ntiles; }
-            for (int p = first_pos; p < P; ++p, ++row) {
+            m.seq_first[nseq] = pt.p0;
+            m.seq_stream[nseq] = r.slot * Q + u;
+            for (int q0 = 0; q0 < pt.p1 - pt.p0; q0 += 64) { m.tiles[2 * ntiles] = nseq; m.tiles[2 * ntiles + 1] = q0; ++ntiles; }
+            for (int p = pt.p0; p < pt.p1; ++p, ++row) {
                 m.row_stream[row] = r.slot * Q + u;
                 m.row_pos[row] = p;
                 m.row_ctx[row] = p + 1;
@@ -629,21 +647,22 @@ int run_prefill(t3_engine* e, const std::vector<Request*>& reqs) {
                     m.ekind[row] = u == 0 ? 1 : 2; m.eidx[row] = r.text[p - kCondRows]; m.eaux[row] = p - kCondRows;
                 } else { m.ekind[row] = 3; m.eidx[row] = 0; m.eaux[row] = 0; }
             }
-            m.a_rows[u * n + i] = row - 1;                  // last prompt row of this stream
+            if (last) m.a_rows[u * n + fin] = row - 1;      // last prompt row of this stream
             ++nseq;
         }
-        m.row_c[i] = i;
-        m.row_u[i] = S == 2 ? n + i : -1;
-        fill_sampling(m, i, r);
+        r.pf_pos = pt.p1;
+        if (!last) continue;
+        m.row_c[fin] = fin;
+        m.row_u[fin] = S == 2 ? n + fin : -1;
+        fill_sampling(m, fin, r);
         // repetition-penalty set starts as the prompt ids of t3.py:229-240
-        const int base = pid;
         m.prompt_ids[pid++] = kCondStart;
         for (int k = 0; k < kCondRows - 2; ++k) m.prompt_ids[pid++] = r.text[0];
         m.prompt_ids[pid++] = kCondEnd;
         for (int k = 0; k < T; ++k) m.prompt_ids[pid++] = r.text[k];
         m.prompt_ids[pid++] = kPrefillEnd;
-        m.step[i] = 0;
-        (void)base;
+        m.step[fin] = 0;
+        ++fin;
     }
     m.seq_start[nseq] = row;
     // An uncond stream without attention has no history: only its last prompt row (the start-of-speech row) reaches the
@@ -651,7 +670,7 @@ int run_prefill(t3_engine* e, const std::vector<Request*>& reqs) {
     const int first_ghost = row;
     if (e->uncond_ghost)
         for (int i = 0; i < n; ++i, ++row) {
-            m.row_stream[row] = -1; m.row_pos[row] = reqs[i]->prompt_len - 1; m.row_ctx[row] = 0;
+            m.row_stream[row] = -1; m.row_pos[row] = reqs_out[i]->prompt_len - 1; m.row_ctx[row] = 0;
             m.ekind[row] = 3; m.eidx[row] = 0; m.eaux[row] = 0;
             m.a_rows[n + i] = row;
         }
@@ -667,8 +686,8 @@ int run_prefill(t3_engine* e, const std::vector<Request*>& reqs) {
     // seen rows
     pid = 0;
     for (int i = 0; i < n; ++i) {
-        const int len = reqs[i]->prompt_len;
-        T3_RUN(e, K_SEEN, -1, (int64_t)kSeenStride, launch_seen_init(e->seen + (size_t)reqs[i]->slot * kSeenStride, kSeenStride,
+        const int len = reqs_out[i]->prompt_len;
+        T3_RUN(e, K_SEEN, -1, (int64_t)kSeenStride, launch_seen_init(e->seen + (size_t)reqs_out[i]->slot * kSeenStride, kSeenStride,
                                                      dev_of(m, m.prompt_ids) + pid, len, e->cur));
         pid += len;
     }
@@ -683,8 +702,9 @@ int run_prefill(t3_engine* e, const std::vector<Request*>& reqs) {
                                     sizeof(bf16_t) * (size_t)(rows - first_ghost) * c.d_model, e->cur));
     if (run_layers(e, rows, dev_of(m, m.row_pos), dev_of(m, m.row_stream), dev_of(m, m.row_ctx), true,
                    dev_of(m, m.seq_start), dev_of(m, m.tiles), ntiles,
-                   share ? dev_of(m, m.seq_pfx) : nullptr)) return 1;
-    if (run_head_and_sample(e, m, n * S, dev_of(m, m.a_rows), n)) return 1;
+                   share ? dev_of(m, m.seq_pfx) : nullptr, nullptr,
+                   chunked ? dev_of(m, m.seq_first) : nullptr, chunked ? dev_of(m, m.seq_stream) : nullptr)) return 1;
+    if (n > 0 && run_head_and_sample(e, m, n * S, dev_of(m, m.a_rows), n)) return 1;
     e->stats.prefill_requests = n;
     e->stats.prefill_rows = rows;
     e->cur = e->stream;
@@ -1101,13 +1121,21 @@ extern "C" int t3_engine_set_schedule_policy(t3_engine* e, int32_t policy) {
     return 0;
 }
 
+extern "C" int t3_engine_set_prefill_chunk(t3_engine* e, int32_t positions) {
+    T3_REQUIRE(e && e->finalized, "engine not finalized");
+    T3_REQUIRE(positions >= 0, "the prefill budget must be 0 (whole prompts) or a number of positions");
+    for (auto& s : e->slots) T3_REQUIRE(!s, "the prefill budget can only change while no request is admitted");
+    e->prefill_chunk = positions;
+    return 0;
+}
+
 extern "C" int t3_engine_abort(t3_engine* e, int64_t req_id) {
     T3_REQUIRE(e, "null argument");
     for (auto it = e->waiting.begin(); it != e->waiting.end(); ++it)
         if ((*it)->id == req_id) { e->waiting.erase(it); return 0; }
     for (auto& s : e->slots)
         if (s && s->id == req_id && !s->zombie) {
-            if (s->n_launched > s->n_out) { s->zombie = true; s->aborted = true; }   // a launched step still uses its pages
+            if (s->n_launched > s->n_out || s->chunks_out > 0) { s->zombie = true; s->aborted = true; }   // a launched step still uses its pages
             else { release_request(e, *s); s.reset(); }
             return 0;
         }
@@ -1196,6 +1224,16 @@ void account_token(t3_engine* e, Request* r, int32_t tok, int64_t* out_req_ids, 
     else { release_request(e, *r); e->slots[r->slot].reset(); }
 }
 
+// The job that carried a chunk of these prompts has completed: they may be scheduled again, and one that was aborted
+// meanwhile gives its slot and pages back now.
+void settle_partial(t3_engine* e, std::vector<Request*>& partial) {
+    for (Request* r : partial) {
+        r->prefilling = false;
+        if (--r->chunks_out == 0 && r->zombie) { release_request(e, *r); e->slots[r->slot].reset(); }
+    }
+    partial.clear();
+}
+
 // Wait for the outstanding prefill job and report the first token of each of its requests; they may decode from now on.
 int report_prefill_job(t3_engine* e, int64_t* out_req_ids, int32_t* out_tokens, int32_t* out_finished, int32_t cap,
                        int32_t* n_out) {
@@ -1211,6 +1249,7 @@ int report_prefill_job(t3_engine* e, int64_t* out_req_ids, int32_t* out_tokens, 
         account_token(e, j.reqs[i], pt[i], out_req_ids, out_tokens, out_finished, k);
     }
     j.reqs.clear();
+    settle_partial(e, j.partial);
     *n_out = k;
     return 0;
 }
@@ -1233,6 +1272,7 @@ int report_inflight(t3_engine* e, int64_t* out_req_ids, int32_t* out_tokens, int
     const int32_t* dt = e->dm[f.parity].out_tokens;
     for (size_t i = 0; i < f.admitted.size(); ++i) account_token(e, f.admitted[i], pt[i], out_req_ids, out_tokens, out_finished, k);
     for (size_t i = 0; i < f.running.size(); ++i) account_token(e, f.running[i], dt[i], out_req_ids, out_tokens, out_finished, k);
+    settle_partial(e, f.partial);
     *n_out = k;
     return 0;
 }
@@ -1273,7 +1313,7 @@ extern "C" int t3_engine_step(t3_engine* e, int64_t* out_req_ids, int32_t* out_t
     // requests with tokens still to launch decode; new ones prefill
     std::vector<Request*> running, admitted;
     for (auto& s : e->slots)
-        if (s && !s->zombie && !s->prefilling && s->n_launched < s->limit) running.push_back(s.get());
+        if (s && !s->zombie && !s->prefilling && s->pf_pos >= s->prompt_len && s->n_launched < s->limit) running.push_back(s.get());
     std::sort(running.begin(), running.end(), [](const Request* a, const Request* b) {
         const int ca = a->prompt_len + a->n_launched, cb = b->prompt_len + b->n_launched;
         return ca != cb ? ca > cb : a->slot < b->slot;
@@ -1290,7 +1330,22 @@ extern "C" int t3_engine_step(t3_engine* e, int64_t* out_req_ids, int32_t* out_t
         }
         running.swap(paired);
     }
-    int row_budget = c.max_prefill_rows;
+    // What this step's prefill job carries.  Whole prompts: new requests while the row budget holds their prompts.  Chunked
+    // (prefill_chunk > 0, the token budget of vLLM's scheduler): prompts already under way come first, then new requests,
+    // and the prompt that does not fit is cut at the budget; it goes on in the next job.
+    const bool chunked = e->prefill_chunk > 0;
+    const int first_pos = e->share_prefix ? kCondRows : 0;
+    int row_budget = chunked ? std::min(e->prefill_chunk, c.max_prefill_rows) : c.max_prefill_rows;
+    std::vector<PrefillPart> parts;
+    std::vector<Request*> partial;
+    if (chunked && !e->pjob.valid)
+        for (auto& s : e->slots) {
+            Request* r = s.get();
+            if (!r || r->zombie || r->prefilling || r->pf_pos >= r->prompt_len || row_budget <= 0) continue;
+            const int p1 = std::min(r->prompt_len, r->pf_pos + row_budget);
+            row_budget -= p1 - r->pf_pos;
+            parts.push_back({r, r->pf_pos, p1});
+        }
     while (!e->waiting.empty() && !e->pjob.valid) {
         Request& r = *e->waiting.front();
         int slot = -1;
@@ -1298,30 +1353,37 @@ extern "C" int t3_engine_step(t3_engine* e, int64_t* out_req_ids, int32_t* out_t
         if (slot < 0) break;
         const int64_t need = (int64_t)r.reserve_pages * e->kv_per_req;
         if ((int64_t)e->free_pages.size() - e->reserved_unallocated < need) break;
-        if (r.prompt_len > row_budget) break;
-        row_budget -= r.prompt_len;
+        if (chunked ? row_budget <= 0 : r.prompt_len > row_budget) break;
+        const int p1 = chunked ? std::min(r.prompt_len, first_pos + row_budget) : r.prompt_len;
+        row_budget -= chunked ? p1 - first_pos : r.prompt_len;
         e->reserved_unallocated += need;
         r.slot = slot;
+        r.pf_pos = first_pos;
         if (e->share_prefix && acquire_voice(e, r)) return 1;
-        admitted.push_back(&r);
+        parts.push_back({&r, first_pos, p1});
         e->slots[slot] = std::move(e->waiting.front());
         e->waiting.pop_front();
     }
+    for (const PrefillPart& pt : parts) if (pt.p1 < pt.r->prompt_len) partial.push_back(pt.r);
 
     const int q = e->parity;
     e->pstream = overlap ? e->pstream_own : e->stream;     // no job is outstanding when this changes
-    if (!admitted.empty()) {
+    if (!parts.empty()) {
         if (e->timing) T3_HIP_CHECK(hipEventRecord(e->ev[0], e->stream));
-        if (run_prefill(e, admitted)) return 1;
+        if (run_prefill(e, parts, admitted)) return 1;     // admitted: the requests whose prompt ends in this job
         if (e->timing) T3_HIP_CHECK(hipEventRecord(e->ev[1], e->stream));
         for (Request* r : admitted) r->n_launched = 1;
+        for (Request* r : partial) r->chunks_out++;
         if (overlap) {                                     // a job of its own: reported by a later call, see above
             T3_HIP_CHECK(hipEventRecord(e->pjob_done, e->pstream));
             for (Request* r : admitted) r->prefilling = true;
+            for (Request* r : partial) r->prefilling = true;
             e->pjob.valid = true;
             e->pjob.parity = q;
             e->pjob.reqs = std::move(admitted);
+            e->pjob.partial = std::move(partial);
             admitted.clear();
+            partial.clear();
         }
     }
     if (!running.empty()) {
@@ -1330,7 +1392,7 @@ extern "C" int t3_engine_step(t3_engine* e, int64_t* out_req_ids, int32_t* out_t
         if (e->timing) T3_HIP_CHECK(hipEventRecord(e->ev[3], e->stream));
         for (Request* r : running) r->n_launched++;
     }
-    const bool launched = !admitted.empty() || !running.empty();
+    const bool launched = !admitted.empty() || !partial.empty() || !running.empty();
     if (launched) T3_HIP_CHECK(hipEventRecord(e->step_done[q], e->stream));
 
     // report the previous step while this one runs (in the synchronous modes it was reported above)
@@ -1339,6 +1401,7 @@ extern "C" int t3_engine_step(t3_engine* e, int64_t* out_req_ids, int32_t* out_t
         e->inflight.valid = true;
         e->inflight.parity = q;
         e->inflight.admitted = std::move(admitted);
+        e->inflight.partial = std::move(partial);
         e->inflight.running = std::move(running);
         e->parity ^= 1;
         if (sync_mode && report_inflight(e, out_req_ids, out_tokens, out_finished, cap, n_out)) return 1;

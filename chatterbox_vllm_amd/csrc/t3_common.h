@@ -258,7 +258,8 @@ int launch_attn_decode_oproj(const bf16_t* qkv, int ldq, float* slab, int rows, 
 // pool page holding keys [0, npfx) when the sequence's rows start at position npfx, or -1 (rows start at 0)
 int launch_attn_prefill(const bf16_t* qkv, int ldq, bf16_t* out, const int32_t* seq_start_dev,
                         const int32_t* tiles_dev, int ntiles, int H, int hd, hipStream_t st,
-                        const int32_t* seq_pfx_dev = nullptr, int npfx = 0, const KvView* kv = nullptr, int layer = 0);
+                        const int32_t* seq_pfx_dev = nullptr, int npfx = 0, const KvView* kv = nullptr, int layer = 0,
+                        const int32_t* seq_first_dev = nullptr, const int32_t* seq_stream_dev = nullptr);
 
 struct EmbedArgs {
     bf16_t* out; int d;                 // [rows, d]

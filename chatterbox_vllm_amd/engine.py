@@ -90,7 +90,8 @@ class T3Engine:
                  cfg_paired: Optional[bool] = None, device: int = 0, enforce_eager: bool = False,
                  kv_pages: int = 0, max_prefill_rows: int = 2048, quantization: Optional[str] = None,
                  scheduling_policy: str = "fcfs", uncond_attends: Optional[bool] = None, prefix_sharing: bool = True,
-                 max_voices: int = 0, stream: Optional[int] = None, **_ignored_vllm_kwargs):
+                 max_voices: int = 0, stream: Optional[int] = None, max_num_batched_tokens: Optional[int] = None,
+                 **_ignored_vllm_kwargs):
         if cfg_scale is None:                      # models/t3/t3.py:343
             cfg_scale = float(os.environ.get("CHATTERBOX_CFG_SCALE", "0.5"))
         if cfg_paired is None:
@@ -133,9 +134,12 @@ class T3Engine:
         else:
             _capi.check(self._lib, self._lib.t3_engine_create_on_stream(C.byref(cfg), C.c_void_p(int(stream)), C.byref(self._h)))
         self.set_schedule_policy(scheduling_policy)
+        self.max_num_batched_tokens = None
         self._next_id = 0
         self._generate_lock = threading.Lock()
         self._load(state_dict)
+        if max_num_batched_tokens:
+            self.set_max_num_batched_tokens(max_num_batched_tokens)
 
     # ---- weights -----------------------------------------------------------------
     def _load_tensor(self, name: str, t: torch.Tensor) -> None:
@@ -217,6 +221,13 @@ class T3Engine:
             raise ValueError("scheduling_policy must be one of " + ", ".join(repr(p) for p in SCHEDULING_POLICIES))
         _capi.check(self._lib, self._lib.t3_engine_set_schedule_policy(self._h, SCHEDULING_POLICIES.index(policy)))
         self.scheduling_policy = policy
+
+    def set_max_num_batched_tokens(self, positions: Optional[int]) -> None:
+        """vLLM's chunked-prefill budget (the reference's engine arguments leave it at vLLM's default; its README shows
+        8192): a prefill job carries at most this many prompt positions per stream and the prompt that does not fit is cut
+        and continued in the next job.  None or 0 = whole prompts.  Tokens do not depend on it.  Only between jobs."""
+        _capi.check(self._lib, self._lib.t3_engine_set_prefill_chunk(self._h, int(positions or 0)))
+        self.max_num_batched_tokens = int(positions) if positions else None
 
     def set_timing(self, on: bool) -> None:
         _capi.check(self._lib, self._lib.t3_engine_set_timing(self._h, int(on)))

@@ -130,6 +130,14 @@ int t3_engine_step(t3_engine* e, int64_t* out_req_ids, int32_t* out_tokens, int3
  * idea for a caller that sets max_tokens per request to the length it expects.  Applies to requests added afterwards;
  * a request's tokens do not depend on what it shares a step with. */
 int t3_engine_set_schedule_policy(t3_engine* e, int32_t policy);
+/* Token budget of a prefill job, the `max_num_batched_tokens` of the vLLM scheduler the reference runs under
+ * (README.md:145 shows 8192; vLLM cuts the prompt that does not fit the rest of a step's budget and continues it in the
+ * next step): positions = 0, the default, sends every prompt through the layers whole (up to max_prefill_rows positions
+ * of whole prompts per job); positions > 0 lets a job carry at most that many positions per stream, prompts already
+ * under way first, and cuts the prompt that does not fit; its later chunks read the earlier ones' keys from the KV pool.
+ * A request's tokens do not depend on where its prompt is cut (the same key tiles, the same values: bit-identical).
+ * Only while no request is admitted. */
+int t3_engine_set_prefill_chunk(t3_engine* e, int32_t positions);
 int t3_engine_abort(t3_engine* e, int64_t req_id);
 int t3_engine_has_unfinished(t3_engine* e);
 int t3_engine_get_stats(t3_engine* e, t3_step_stats* out);

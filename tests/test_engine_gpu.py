@@ -944,6 +944,83 @@ def test_bench_launches_two_ranks_by_itself():
     assert rec["config"]["requests_per_gpu"] == 8 and rec["value"] > 0
     assert abs(rec["per_gpu_tokens_per_s"] * 2 - rec["value"]) < 1.0
 
+@pytest.mark.parametrize("kw", [dict(), dict(prefix_sharing=False), dict(uncond_attends=False), dict(cfg_paired=False)],
+                         ids=["shared_prefix", "private_prefix", "uncond_without_attention", "single_stream"])
+def test_chunked_prompts_give_the_bits_of_whole_prompts(small, kw):
+    """vLLM's token budget for prompt steps (max_num_batched_tokens; a prompt that does not fit the rest of a step's budget is
+    cut and continued in the next step): with budgets of 40, 64 and 150 positions the prompts below (37 to 336 positions, three
+    voices) go through the layers in up to nine pieces, whose later ones read the earlier ones' keys from the KV pool.  Ids
+    and every logit must be the bits of the engine that sends prompts whole, step by step with logit taps and again through
+    generate() (prefill jobs on their own stream beside the decode steps)."""
+    cfg, sd = small
+    texts = [_text(n, 300 + n) for n in (300, 2, 61, 130, 29, 200)]
+    voices = [0, 1, 1, 2, 0, 2]
+    sp = SamplingParams(temperature=0.0, repetition_penalty=2.0, max_tokens=12, stop_token_ids=[STOP])
+    paired = kw.get("cfg_paired", True)
+    items = _items(texts, voices)
+
+    def run(budget):
+        eng = T3Engine(cfg, sd, max_model_len=400, max_num_seqs=4, cfg_scale=3.0 if paired else 0.0, max_num_batched_tokens=budget, **kw)
+        ids, logits, fins = _run_with_logits(eng, items, sp)
+        plain = [o.outputs[0].token_ids for o in eng.generate(items, sp)]
+        jobs = 0
+        if budget:                                           # the budget is kept: no prefill job carries more positions per stream
+            rids = [eng.add_request(it["prompt_token_ids"], it["multi_modal_data"]["conditionals"][0], sp) for it in items]
+            per_stream = 2 if (paired and kw.get("uncond_attends", True)) else 1
+            extra = 34 * 3 * per_stream                      # the rows of voices built in a job ride on top of the budget
+            while eng.has_unfinished():
+                eng.step()
+                rows = eng.stats().prefill_rows
+                jobs += int(rows > 0)
+                assert rows <= budget * per_stream + extra + 4, f"a prefill job of {rows} rows under a budget of {budget}"
+            del rids
+        eng.shutdown()
+        return ids, logits, fins, plain, jobs
+
+    want_ids, want_logits, want_fins, want_plain, _ = run(None)
+    assert want_plain == want_ids
+    for budget in (40, 64, 150):
+        ids, logits, fins, plain, jobs = run(budget)
+        assert ids == want_ids and plain == want_ids and fins == want_fins, f"budget {budget}: ids differ from whole prompts"
+        for a, b in zip(logits, want_logits):
+            assert len(a) == len(b) and all(torch.equal(x, y) for x, y in zip(a, b)), f"budget {budget}: logits differ"
+        assert jobs >= sum(len(t) for t in texts) // budget, f"budget {budget}: only {jobs} prefill jobs"
+
+
+def test_abort_between_and_during_the_chunks_of_a_prompt(small):
+    """A request aborted while its prompt is half way through the layers (between two prefill jobs, and while a job that
+    carries one of its chunks is still running) gives back its slot and every KV page, and the others' ids are those of a
+    run without it."""
+    cfg, sd = small
+    texts = [_text(n, 500 + n) for n in (250, 40, 180)]
+    sp = SamplingParams(temperature=0.0, repetition_penalty=2.0, max_tokens=10, stop_token_ids=[STOP])
+    items = _items(texts, [0, 1, 2])
+    ref = T3Engine(cfg, sd, max_model_len=400, max_num_seqs=4, cfg_scale=3.0)
+    want = [o.outputs[0].token_ids for o in ref.generate(items[1:], sp)]
+    ref.shutdown()
+    for steps_before_abort in (1, 2, 3):
+        eng = T3Engine(cfg, sd, max_model_len=400, max_num_seqs=4, cfg_scale=3.0, max_num_batched_tokens=48)
+        free0 = None
+        rids = [eng.add_request(it["prompt_token_ids"], it["multi_modal_data"]["conditionals"][0], sp) for it in items]
+        got = {r: [] for r in rids}
+        for _ in range(steps_before_abort):
+            for rid, tok, fin in eng.step():
+                got[rid].append(tok)
+        eng.abort(rids[0])
+        while eng.has_unfinished():
+            for rid, tok, fin in eng.step():
+                got[rid].append(tok)
+        st = eng.stats()
+        assert st.running == 0 and st.waiting == 0
+        # every page is free again: a fresh long request is admitted and runs
+        again = eng.generate(items[:1], sp)[0].outputs[0].token_ids
+        assert len(again) == 10
+        if free0 is None:
+            free0 = eng.stats().free_pages
+        eng.shutdown()
+        assert [got[r] for r in rids[1:]] == want and got[rids[0]] == []
+
+
 
 def test_bench_runs_its_rccl_collectives_with_one_rank():
     """bench.py under torch.distributed.run with ONE rank and --force-dist: the process group is RCCL (backend "nccl"), and the

@@ -21,8 +21,10 @@ def main():
     ap.add_argument("--batch", type=int, nargs="+", default=[1, 2, 4, 8])
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--ragged", action="store_true", help="utterance u of a batch gets frames * (1 - 0.05 u)")
+    ap.add_argument("--split-bf16", action="store_true", help="attention launches on split-bf16 operands")
     args = ap.parse_args()
-    cfm = CausalConditionalCFM(CW.synthetic_state_dict(), max_frames=max(args.frames), max_batch=max(args.batch))
+    cfm = CausalConditionalCFM(CW.synthetic_state_dict(), max_frames=max(args.frames), max_batch=max(args.batch),
+                               split_bf16=args.split_bf16)
     ts = CW.t_span(10)
     for L in args.frames:
         d = CW.synthetic_inputs(L, L // 2)

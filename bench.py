@@ -245,7 +245,7 @@ def make_engine(cfg, sd, conc, paired, device, args, quantization, policy, uncon
                     cfg_paired=paired, device=device, max_prefill_rows=args.max_prefill_rows,
                     quantization=None if quantization == "none" else quantization,
                     scheduling_policy=policy, uncond_attends=uncond_attends,
-                    prefix_sharing=not args.no_prefix_sharing)
+                    prefix_sharing=not args.no_prefix_sharing, max_num_batched_tokens=args.max_num_batched_tokens or None)
 
 
 FP32_MFMA_PEAK_TFLOPS = 157.3     # v_mfma_f32_32x32x2_f32, 64 FLOP per clock and SIMD, 1024 SIMDs at 2.4 GHz
@@ -610,6 +610,9 @@ def main():
     ap.add_argument("--concurrency", type=int, default=0, help="requests decoded together per job (default 32; single: 1)")
     ap.add_argument("--quantization", choices=["none", "int8"], default="none")
     ap.add_argument("--repeat-job", type=int, default=1, help="queue the request list this many times per step")
+    ap.add_argument("--max-num-batched-tokens", type=int, default=0,
+                    help="vLLM's token budget for prompt steps: a prefill job carries at most this many positions per stream and "
+                         "cuts the prompt that does not fit (0 = whole prompts, the default; tokens do not depend on it)")
     ap.add_argument("--policy", choices=["fcfs", "longest_prompt_first", "longest_first"], default="longest_prompt_first",
                     help="admission order of the queue.  longest_prompt_first (default) ranks the waiting requests by "
                          "prompt length alone, which every caller knows; it keeps the 32 slots full until the queue is "

@@ -1,4 +1,4 @@
-"""Scheduler soak: random arrivals, aborts, voices, slot counts, pool sizes, eager/graph, all three admission orders;
+"""Scheduler soak: random arrivals, aborts, voices, slot counts, pool sizes, eager/graph, all three admission orders, whole and chunked prompts;
 every surviving request must end with the ids of a solo run and the KV pool must drain.  python tools/soak_scheduler.py FIRST_SEED END_SEED"""
 import os, sys, random, torch
 sys.path.insert(0, os.getcwd())
@@ -32,7 +32,8 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     slots = rng.choice([2, 3, 6, 8])
     pool = slots * 2 * 3 - rng.choice([0, 3])
     eng = T3Engine(cfg, sd, max_model_len=192, max_num_seqs=slots, cfg_scale=3.0, kv_pages=max(pool, 6),
-                   enforce_eager=rng.random() < 0.3, scheduling_policy=rng.choice(["fcfs", "longest_first", "longest_prompt_first"]))
+                   enforce_eager=rng.random() < 0.3, scheduling_policy=rng.choice(["fcfs", "longest_first", "longest_prompt_first"]),
+                   max_num_batched_tokens=rng.choice([None, None, 24, 40, 64]))
     got, rid_of, aborted = {}, {}, set()
     step = nxt = 0
     while nxt < n or eng.has_unfinished():

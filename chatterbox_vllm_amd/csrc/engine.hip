@@ -224,7 +224,7 @@ struct t3_engine {
                 *seq_start, *seq_pfx, *seq_first, *seq_stream, *tiles, *prompt_ids, *out_tokens = nullptr;   // host views (out_tokens: its own pinned buffer)
         float *rep, *temp, *top_p, *min_p;
         uint64_t* seed;
-        size_t rows_cap = 0, req_cap = 0;
+        size_t rows_cap = 0, req_cap = 0, ids_cap = 0, seq_cap = 0, tile_cap = 0;
     } dm[2], pm[2];                                      // decode / prefill, by step parity
     int32_t* bt_stage[2] = {nullptr, nullptr};          // pinned snapshots of the block table, by step parity
 
@@ -288,9 +288,10 @@ int ktime_end(t3_engine* e);
     } while (0)
 
 int meta_alloc(t3_engine::Meta& m, size_t rows, size_t reqs, size_t prompt_ids) {
-    m.rows_cap = rows; m.req_cap = reqs;
+    m.rows_cap = rows; m.req_cap = reqs; m.ids_cap = prompt_ids;
     // sequences of a prefill step: up to two streams per request plus one per voice built in the step
     const size_t seqs = 3 * reqs + 2, tiles = rows / 32 + 5 * reqs + 64;
+    m.seq_cap = seqs - 1; m.tile_cap = tiles;
     const size_t ni = rows * 7 + reqs * 5 + reqs * 2 /*a_rows*/ + 4 * seqs + 2 * tiles + prompt_ids + 64;
     const size_t nu = reqs + 4, nf = reqs * 4 + 16;
     if (m.blk.alloc(sizeof(uint64_t) * nu + sizeof(float) * nf + sizeof(int32_t) * ni)) return 1;
@@ -601,6 +602,19 @@ int run_prefill(t3_engine* e, const std::vector<PrefillPart>& parts, std::vector
     reqs_out.clear();
     for (const PrefillPart& pt : parts) if (pt.p1 == pt.r->prompt_len) reqs_out.push_back(pt.r);
     const int n = (int)reqs_out.size();                   // requests that reach the sampler
+    {   // the job must fit the step's metadata and activation buffers: checked before anything is written
+        size_t need_rows = e->uncond_ghost ? (size_t)n : 0, need_ids = 0, need_seqs = 0, need_tiles = 0;
+        for (const PrefillPart& pt : parts) {
+            T3_REQUIRE(pt.p0 >= 0 && pt.p0 < pt.p1 && pt.p1 <= pt.r->prompt_len, "prefill job: bad position range");
+            need_rows += (size_t)(pt.p1 - pt.p0) * Q;
+            need_seqs += Q;
+            need_tiles += (size_t)Q * ((pt.p1 - pt.p0 + 63) / 64);
+            if (share && pt.r->builds_voice) { need_rows += kCondRows; need_seqs += 1; need_tiles += 1; }
+            if (pt.p1 == pt.r->prompt_len) need_ids += pt.r->prompt_len;
+        }
+        T3_REQUIRE(need_rows <= m.rows_cap && need_rows <= (size_t)e->max_rows && need_ids <= m.ids_cap && need_seqs <= m.seq_cap &&
+                   need_tiles <= m.tile_cap && (size_t)n <= m.req_cap, "prefill job larger than the step's buffers");
+    }
     // the prompts run on the prefill stream, behind everything the main stream holds so far
     e->cur = e->pstream;
     e->b = &e->pbufs;
@@ -910,7 +924,8 @@ static int engine_create(const t3_config* cfg, hipStream_t caller_stream, bool o
                            sizeof(float) * c.max_num_seqs * (size_t)(c.speech_vocab + kOffset)));
     for (int q = 0; q < 2; ++q) {
         if (meta_alloc(e->dm[q], e->n_rows, c.max_num_seqs, 16)) return 1;
-        if (meta_alloc(e->pm[q], prefill_rows, c.max_num_seqs, (size_t)c.max_prefill_rows + (size_t)c.max_num_seqs * 64)) return 1;
+        if (meta_alloc(e->pm[q], prefill_rows, c.max_num_seqs,
+                       (size_t)c.max_prefill_rows + (size_t)c.max_model_len + (size_t)c.max_num_seqs * 64)) return 1;
     }
     for (auto& ev : e->ev) T3_HIP_CHECK(hipEventCreate(&ev));
     T3_HIP_CHECK(hipEventCreateWithFlags(&e->pjob_done, hipEventDisableTiming));
@@ -1335,16 +1350,21 @@ extern "C" int t3_engine_step(t3_engine* e, int64_t* out_req_ids, int32_t* out_t
     // and the prompt that does not fit is cut at the budget; it goes on in the next job.
     const bool chunked = e->prefill_chunk > 0;
     const int first_pos = e->share_prefix ? kCondRows : 0;
-    int row_budget = chunked ? std::min(e->prefill_chunk, c.max_prefill_rows) : c.max_prefill_rows;
+    // two limits: the token budget (positions per stream a chunked job may carry) and the room of the job's buffers
+    // (max_prefill_rows positions per stream; the 34 rows of a voice that a request's first chunk builds count against it,
+    // and whole prompts count their 34 prefix positions although a shared prefix leaves them out of the rows)
+    int chunk_left = chunked ? e->prefill_chunk : c.max_prefill_rows;
+    int rows_left = c.max_prefill_rows;
     std::vector<PrefillPart> parts;
     std::vector<Request*> partial;
     if (chunked && !e->pjob.valid)
         for (auto& s : e->slots) {
             Request* r = s.get();
-            if (!r || r->zombie || r->prefilling || r->pf_pos >= r->prompt_len || row_budget <= 0) continue;
-            const int p1 = std::min(r->prompt_len, r->pf_pos + row_budget);
-            row_budget -= p1 - r->pf_pos;
-            parts.push_back({r, r->pf_pos, p1});
+            if (!r || r->zombie || r->prefilling || r->pf_pos >= r->prompt_len) continue;
+            const int take = std::min(r->prompt_len - r->pf_pos, std::min(chunk_left, rows_left));
+            if (take <= 0) break;
+            chunk_left -= take; rows_left -= take;
+            parts.push_back({r, r->pf_pos, r->pf_pos + take});
         }
     while (!e->waiting.empty() && !e->pjob.valid) {
         Request& r = *e->waiting.front();
@@ -1353,14 +1373,20 @@ extern "C" int t3_engine_step(t3_engine* e, int64_t* out_req_ids, int32_t* out_t
         if (slot < 0) break;
         const int64_t need = (int64_t)r.reserve_pages * e->kv_per_req;
         if ((int64_t)e->free_pages.size() - e->reserved_unallocated < need) break;
-        if (chunked ? row_budget <= 0 : r.prompt_len > row_budget) break;
-        const int p1 = chunked ? std::min(r.prompt_len, first_pos + row_budget) : r.prompt_len;
-        row_budget -= chunked ? p1 - first_pos : r.prompt_len;
+        if (chunked ? (chunk_left <= 0 || rows_left <= first_pos) : r.prompt_len > rows_left) break;
         e->reserved_unallocated += need;
         r.slot = slot;
         r.pf_pos = first_pos;
         if (e->share_prefix && acquire_voice(e, r)) return 1;
-        parts.push_back({&r, first_pos, p1});
+        int take = r.prompt_len - first_pos;
+        if (chunked) {
+            if (e->share_prefix && r.builds_voice) rows_left -= kCondRows;
+            take = std::min(take, std::min(chunk_left, rows_left));       // >= 1: rows_left was above 34
+            chunk_left -= take; rows_left -= take;
+        } else {
+            rows_left -= r.prompt_len;
+        }
+        parts.push_back({&r, first_pos, first_pos + take});
         e->slots[slot] = std::move(e->waiting.front());
         e->waiting.pop_front();
     }

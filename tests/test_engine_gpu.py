@@ -987,6 +987,33 @@ def test_chunked_prompts_give_the_bits_of_whole_prompts(small, kw):
         assert jobs >= sum(len(t) for t in texts) // budget, f"budget {budget}: only {jobs} prefill jobs"
 
 
+def test_a_budget_as_large_as_the_job_buffers_keeps_room_for_the_voice_rows(small):
+    """The token budget may equal the room of a prefill job's buffers (max_prefill_rows positions per stream).  The 34 rows
+    of every voice that a job builds ride in the same buffers, so a job then carries fewer prompt positions than the budget
+    allows; ids stay those of whole prompts, and no job exceeds the buffers (the engine checks that before it writes a
+    job's metadata and reports an error instead of running it)."""
+    cfg, sd = small
+    texts = [_text(n, 700 + n) for n in (330, 300, 250, 280, 120, 310, 90, 200)]
+    voices = [0, 1, 2, 3, 4, 0, 1, 5]
+    sp = SamplingParams(temperature=0.0, repetition_penalty=2.0, max_tokens=6, stop_token_ids=[STOP])
+    items = _items(texts, voices)
+    ref = T3Engine(cfg, sd, max_model_len=400, max_num_seqs=8, cfg_scale=3.0)
+    want = [o.outputs[0].token_ids for o in ref.generate(items, sp)]
+    ref.shutdown()
+    for budget in (400, 100000):
+        eng = T3Engine(cfg, sd, max_model_len=400, max_num_seqs=8, cfg_scale=3.0, max_prefill_rows=400, max_num_batched_tokens=budget)
+        got = [o.outputs[0].token_ids for o in eng.generate(items, sp)]
+        rids = [eng.add_request(it["prompt_token_ids"], it["multi_modal_data"]["conditionals"][0], sp) for it in items]
+        most = 0
+        while eng.has_unfinished():
+            eng.step()
+            most = max(most, eng.stats().prefill_rows)
+        eng.shutdown()
+        assert got == want
+        assert 600 < most <= 2 * 400, f"the largest prefill job carried {most} rows"
+        del rids
+
+
 def test_abort_between_and_during_the_chunks_of_a_prompt(small):
     """A request aborted while its prompt is half way through the layers (between two prefill jobs, and while a job that
     carries one of its chunks is still running) gives back its slot and every KV page, and the others' ids are those of a

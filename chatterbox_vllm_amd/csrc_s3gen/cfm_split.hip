@@ -90,9 +90,9 @@ __device__ __forceinline__ float half_sum(float x) {
 // the probabilities sit where the second product wants its B operand.  Per key tile and query tile: 24 + 24 matrix
 // instructions of 32 cycles against 32 + 32 of 64, so the vector work of a tile (softmax, splitting the probabilities:
 // about 190 instructions per query tile) is as long as its matrix work and must run under it: the loop is software-pipelined,
-// the scores of the wave's NEXT key tile (matrix instructions that depend on nothing computed here) are issued in the same
-// basic block as the softmax of the current one, without branches, so that the compiler interleaves the two streams.  The
-// key mask is only ever needed on a wave's last tile, which is peeled off the loop.
+// each half of a tile's softmax sits in one basic block with matrix instructions that do not depend on it (the scores of the
+// wave's NEXT key tile, the second product of the CURRENT one), without branches, so that the compiler interleaves the two
+// streams.  The key mask is only ever needed on a wave's last tile, which is peeled off the loop.
 template <int QT>
 __global__ __launch_bounds__(256) void attn_split_kernel(const unsigned short* __restrict__ lead_qp, const unsigned short* __restrict__ lead_kp,
                                                          const unsigned short* __restrict__ lead_vp, int lead_ld, int lead_L, int lead_rows,
@@ -166,23 +166,46 @@ __global__ __launch_bounds__(256) void attn_split_kernel(const unsigned short* _
 #pragma unroll
             for (int u = 0; u < QT; ++u) MFMA_SPLIT6(K[s], Q[u][s], dst[u]);
     };
-    // online softmax of query tile u on the scores in s[u], then the probabilities as operand planes: accumulators
-    // 8 t2 .. 8 t2 + 7 of a lane are the eight keys of depth step t2 in the order V was written in.  No branch (the rescale
-    // of the output accumulators is unconditional), so that the whole of it can be scheduled among the matrix instructions
-    // of the next tile's scores.
-    auto softmax = [&](int u, f32x16 (&s)[QT]) {
+    // The online softmax of a key tile is cut in two, so that each half can sit among the matrix instructions of one of the
+    // two products (no branches in either):
+    //   stats:  tile maximum, the softmax reference to use, probabilities (in place of the scores), their sum;
+    //   finish: running sum, the probabilities as operand planes (accumulators 8 t2 .. 8 t2 + 7 of a lane are the eight
+    //           keys of depth step t2 in the order V was written in).
+    // The softmax reference m of a query follows its running maximum in jumps: it moves only when a tile's maximum lies more
+    // than 16 units of ln 2 above it (probabilities then reach 2^16 at most, far from any fp32 limit; relative precision does
+    // not depend on the reference).  After a wave's first tile that is rare, so the rescale of the output accumulators sits
+    // under a wave-uniform branch that is almost never taken, ahead of the block, and the accumulators otherwise stay in the
+    // registers the matrix instructions keep them in (with an unconditional rescale they were moved to the vector registers
+    // and back every tile: 64 multiplies and 128 moves per tile among 590 vector instructions).
+    float m_new[QT], psum[QT];
+    auto stats = [&](int u, f32x16 (&s)[QT]) {
         float mx = s[u][0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[u][r]);
-        const float m_new = fmaxf(m[u], half_max(mx));         // finite: every tile holds a key below Lk
+        mx = half_max(mx);                                     // finite: every tile holds a key below Lk
+        m_new[u] = mx > m[u] + 16.0f ? mx : m[u];
         float ps = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { s[u][r] = __builtin_amdgcn_exp2f(s[u][r] - m_new); ps += s[u][r]; }
-        const float alpha = __builtin_amdgcn_exp2f(m[u] - m_new);
-        l[u] = l[u] * alpha + half_sum(ps);
+        for (int r = 0; r < 16; ++r) { s[u][r] = __builtin_amdgcn_exp2f(s[u][r] - m_new[u]); ps += s[u][r]; }
+        psum[u] = half_sum(ps);
+    };
+    auto move_reference = [&]() {
+        bool moved = false;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { o0[u][i] *= alpha; o1[u][i] *= alpha; }
-        m[u] = m_new;
+        for (int u = 0; u < QT; ++u) moved |= m_new[u] != m[u];
+        if (__any(moved)) {
+#pragma unroll
+            for (int u = 0; u < QT; ++u) {
+                const float alpha = __builtin_amdgcn_exp2f(m[u] - m_new[u]);     // 1 where the reference stays, 0 on the first tile
+                l[u] *= alpha;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { o0[u][i] *= alpha; o1[u][i] *= alpha; }
+                m[u] = m_new[u];
+            }
+        }
+    };
+    auto finish = [&](int u, const f32x16 (&s)[QT]) {
+        l[u] += psum[u];
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
@@ -206,39 +229,70 @@ __global__ __launch_bounds__(256) void attn_split_kernel(const unsigned short* _
                 }
     };
     int t = w;
-    if (t < ntiles) {
-        load_k(t);
-        load_v(t);
-        scores(sc);
-        __builtin_amdgcn_sched_barrier(0);
-        if (t + 4 < ntiles) load_k(t + 4);
-        for (; t + 4 < ntiles; t += 4) {
-            // the scores of tile t + 4 are issued in the same basic block as the softmax of tile t
-            __builtin_amdgcn_sched_barrier(0);
-            scores(sn);
-#pragma unroll
-            for (int u = 0; u < QT; ++u) softmax(u, sc);
-            __builtin_amdgcn_sched_barrier(0);
-            load_k(t + 8 < ntiles ? t + 8 : t + 4);            // a wave's last tile loads itself again: no branch
-            __builtin_amdgcn_sched_barrier(0);
-            second_product();
-            __builtin_amdgcn_sched_barrier(0);
-            load_v(t + 4);
-#pragma unroll
-            for (int u = 0; u < QT; ++u) sc[u] = sn[u];
-        }
-        // the wave's last tile: the only one that can hold keys past Lk
-        const int key0 = t * 32;
+    auto mask_tail = [&](f32x16 (&s)[QT], int tile) {          // only a wave's last tile can hold keys past Lk
+        const int key0 = tile * 32;
         if (key0 + 32 > Lk) {
 #pragma unroll
             for (int u = 0; u < QT; ++u)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    if (key0 + 8 * (r >> 2) + 4 * half + (r & 3) >= Lk) sc[u][r] = -INFINITY;
+                    if (key0 + 8 * (r >> 2) + 4 * half + (r & 3) >= Lk) s[u][r] = -INFINITY;
         }
+    };
+    if (t < ntiles) {
+        load_k(t);
+        load_v(t);
+        scores(sc);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 4 >= ntiles) {                                 // the wave's only tile
+            mask_tail(sc, t);
 #pragma unroll
-        for (int u = 0; u < QT; ++u) softmax(u, sc);
-        second_product();
+            for (int u = 0; u < QT; ++u) stats(u, sc);
+            move_reference();
+#pragma unroll
+            for (int u = 0; u < QT; ++u) finish(u, sc);
+            second_product();
+        } else {
+            load_k(t + 4);
+#pragma unroll
+            for (int u = 0; u < QT; ++u) stats(u, sc);
+            // Steady state, two basic blocks per key tile, each with half of the softmax among one product's matrix
+            // instructions: [scores of tile t + 4 | finish of tile t] and [second product of tile t | stats of tile t + 4].
+            for (; t + 8 < ntiles; t += 4) {
+                move_reference();
+                __builtin_amdgcn_sched_barrier(0);
+                scores(sn);
+#pragma unroll
+                for (int u = 0; u < QT; ++u) finish(u, sc);
+                __builtin_amdgcn_sched_barrier(0);
+                load_k(t + 8);
+                __builtin_amdgcn_sched_barrier(0);
+                second_product();
+#pragma unroll
+                for (int u = 0; u < QT; ++u) stats(u, sn);
+                __builtin_amdgcn_sched_barrier(0);
+                load_v(t + 4);
+#pragma unroll
+                for (int u = 0; u < QT; ++u) sc[u] = sn[u];
+            }
+            // tile t + 4 is the wave's last one
+            move_reference();
+            __builtin_amdgcn_sched_barrier(0);
+            scores(sn);
+#pragma unroll
+            for (int u = 0; u < QT; ++u) finish(u, sc);
+            __builtin_amdgcn_sched_barrier(0);
+            second_product();
+            __builtin_amdgcn_sched_barrier(0);
+            load_v(t + 4);
+            mask_tail(sn, t + 4);
+#pragma unroll
+            for (int u = 0; u < QT; ++u) stats(u, sn);
+            move_reference();
+#pragma unroll
+            for (int u = 0; u < QT; ++u) finish(u, sn);
+            second_product();
+        }
     }
     // merge the four waves' partial results, one query tile at a time through the same 32 KiB
 #pragma unroll

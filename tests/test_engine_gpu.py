@@ -706,6 +706,12 @@ def test_long_context_30_layers_equals_the_golden():
     eng.shutdown()
     assert ids[0] == want, "ids differ from the long-context golden"
     assert plain[0].outputs[0].token_ids == want
+    # the same prompt cut into pieces of at most 100 positions (six prefill jobs whose later ones read the earlier ones' keys
+    # from the KV pool): the golden's ids again
+    cut = T3Engine(cfg, sd, max_model_len=int(z["max_model_len"]), max_num_seqs=2, cfg_scale=s, max_num_batched_tokens=100)
+    chunked = cut.generate(_items([text, _text(30, 5)], [voice, 0]), sp)
+    cut.shutdown()
+    assert chunked[0].outputs[0].token_ids == want, "ids of the chunked prompt differ from the long-context golden"
     worst = 0.0
     for step, row in zip(z["logit_steps"], torch.from_numpy(z["logit_rows"])):
         got = logits[0][step][1000:]

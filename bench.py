@@ -352,19 +352,21 @@ def flow_decoder_leg(device, frames=1000, n_timesteps=10, iters=3, per_call=8):
     e1.record()
     torch.cuda.synchronize(device)
     ev8_ms = e0.elapsed_time(e1)
-    # the same solve with the attention launches on split-bf16 operands (s3cfm_set_split_bf16): a labelled extra, the fp32
-    # matrix instruction stays the leg's value; its distance from the fp32 form's result is reported with it
+    # the same solve with the matrix launches on split-bf16 operands (s3cfm_set_split_bf16: 1 = attention, 2 = linear layers and
+    # convolutions too): labelled extras, the fp32 matrix instruction stays the leg's value; each one's distance from the fp32
+    # form's result is reported with it
     ref32 = m.solve_euler(inp["noise"], ts, inp["mu"], inp["spks"], inp["cond"])
-    m.set_split_bf16(True)
-    got_split = m.solve_euler(inp["noise"], ts, inp["mu"], inp["spks"], inp["cond"])
-    torch.cuda.synchronize(device)
-    e0.record()
-    for _ in range(iters):
-        m.solve_euler(inp["noise"], ts, inp["mu"], inp["spks"], inp["cond"])
-    e1.record()
-    torch.cuda.synchronize(device)
-    split_ms = e0.elapsed_time(e1) / iters
-    split_diff = ((got_split - ref32).abs().max() / ref32.abs().max()).item()
+    split_runs = []
+    for mode, label in ((1, "attention"), (2, "attention, linear layers and convolutions")):
+        m.set_split_bf16(mode)
+        got_split = m.solve_euler(inp["noise"], ts, inp["mu"], inp["spks"], inp["cond"])
+        torch.cuda.synchronize(device)
+        e0.record()
+        for _ in range(iters):
+            m.solve_euler(inp["noise"], ts, inp["mu"], inp["spks"], inp["cond"])
+        e1.record()
+        torch.cuda.synchronize(device)
+        split_runs.append((label, e0.elapsed_time(e1) / iters, ((got_split - ref32).abs().max() / ref32.abs().max()).item()))
     m.shutdown()
     flop = CW.estimator_flop(frames) * n_timesteps
     achieved = flop / (ev_ms * 1e-3) / 1e12
@@ -378,11 +380,12 @@ def flow_decoder_leg(device, frames=1000, n_timesteps=10, iters=3, per_call=8):
     rec["several_per_call"] = {"utterances_per_call": per_call, "value": round(per_call * frames * 0.02 / (ev8_ms * 1e-3), 1),
                                "event_ms_per_call": round(ev8_ms, 3), "achieved": round(per_call * flop / (ev8_ms * 1e-3) / 1e12, 2),
                                "frac": round(per_call * flop / (ev8_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)}
-    rec["split_bf16_attention"] = {"value": round(frames * 0.02 / (split_ms * 1e-3), 1), "event_ms_per_call": round(split_ms, 3),
-                                   "max_difference_from_the_fp32_form": float(f"{split_diff:.2e}"),
-                                   "note": "attention operands as three bf16 values each, six partial products per product on the bf16 "
-                                           "matrix instruction, fp32 accumulation; held to the fp32 form's tolerances against fp64 "
-                                           "(tests/test_cfm_gpu.py runs every decoder test in both forms); off by default"}
+    rec["split_bf16"] = {"note": "fp32 operands as three bf16 values each, six partial products per product on the bf16 matrix instruction, "
+                                 "fp32 accumulation; held to the fp32 form's tolerances against fp64 (tests/test_cfm_gpu.py runs every "
+                                 "decoder test in all forms); off by default",
+                         "forms": [{"launches": label, "value": round(frames * 0.02 / (ms * 1e-3), 1), "event_ms_per_call": round(ms, 3),
+                                    "fp32_equivalent_tflops": round(flop / (ms * 1e-3) / 1e12, 1),
+                                    "max_difference_from_the_fp32_form": float(f"{diff:.2e}")} for label, ms, diff in split_runs]}
     from oracle import cfm_oracle as CO
     small = frames
     inp_c = CW.synthetic_inputs(small, small // 3)
@@ -435,7 +438,7 @@ def token_to_waveform_leg(device, prompt_tokens=250, new_tokens=250, iters=3):
             "parity": "encoder, flow decoder and vocoder pinned by reference outputs (flow decoder: the inside of three diffusers classes unpinned)"}
 
 
-def s3gen_job_leg(device, lengths, prompt_tokens=250, variants=((2, 4), (1, 1), (1, 8), (3, 4), (2, 4, True))):
+def s3gen_job_leg(device, lengths, prompt_tokens=250, variants=((2, 4), (1, 1), (1, 8), (3, 4), (2, 4, 2))):
     """The second half of the reference's benchmark.py for the same job: every chunk's speech tokens through the token ->
     waveform chain with a 10 s voice prompt.  The token counts are the ones the T3 leg generated for the job's chunks; the
     token values and all weights are seeded synthetic.  `variants` are (copies of the chain in flight, utterances per
@@ -443,8 +446,8 @@ def s3gen_job_leg(device, lengths, prompt_tokens=250, variants=((2, 4), (1, 1), 
     launches, several copies (each with its own weights, workspace, stream and host thread) use the CUs that one copy's
     launches leave idle; chunks are handed out longest first.  `value` is the FIRST variant, (2, 4): the schedule the
     facade builds by default (ChatterboxTTS.from_local / from_synthetic).  (1, 1) is one utterance at a time, as the
-    reference runs it (tts.py:428-557).  A third entry True repeats a schedule with the flow-matching decoder's attention
-    on split-bf16 operands (off by default; reported as `split_bf16_attention`, never as `value`).  Reported beside the T3 time so that the whole text -> waveform job has a number
+    reference runs it (tts.py:428-557).  A third entry 1 or 2 repeats a schedule with the flow-matching decoder's attention
+    (1) or all its matrix launches (2) on split-bf16 operands (off by default; reported as `split_bf16`, never as `value`).  Reported beside the T3 time so that the whole text -> waveform job has a number
     (the reference's README reports the two times for its run, README.md:150-153)."""
     from chatterbox_vllm_amd import cfm_weights as CW, flow_weights as FW, hift_weights as HW
     from chatterbox_vllm_amd.s3gen import S3Token2Wav
@@ -461,7 +464,7 @@ def s3gen_job_leg(device, lengths, prompt_tokens=250, variants=((2, 4), (1, 1), 
     longest = sorted(range(len(toks)), key=lambda i: -lengths[i])
     runs = []
     for var in variants:
-        nw, nb, split = var[0], var[1], len(var) > 2 and bool(var[2])
+        nw, nb, split = var[0], var[1], (int(var[2]) if len(var) > 2 else 0)
         s3 = S3Token2Wav(flow_sd, hift_sd, max_tokens=prompt_tokens + max(lengths), device=device, max_batch=nb, chains=nw,
                          split_bf16=split)
         s3.render_many([toks[i] for i in longest[:2 * nw * nb]], ref)          # warm-up of every copy
@@ -484,8 +487,9 @@ def s3gen_job_leg(device, lengths, prompt_tokens=250, variants=((2, 4), (1, 1), 
     rec["variants"] = [{k: v for k, v in r.items() if k not in ("audio_seconds", "split")} for r in runs[1:] if not r["split"]]
     sp = next((r for r in runs if r["split"]), None)
     if sp:
-        rec["split_bf16_attention"] = {"utterances_in_flight": sp["utterances_in_flight"], "utterances_per_call": sp["utterances_per_call"],
-                                       "seconds": sp["seconds"], "value": sp["value"]}
+        rec["split_bf16"] = {"launches": "attention" if sp["split"] == 1 else "attention, linear layers and convolutions",
+                             "utterances_in_flight": sp["utterances_in_flight"], "utterances_per_call": sp["utterances_per_call"],
+                             "seconds": sp["seconds"], "value": sp["value"]}
     rec["one_utterance_at_a_time_seconds"] = next((r["seconds"] for r in runs if (r["utterances_in_flight"], r["utterances_per_call"]) == (1, 1)
                                                    and not r["split"]), None)
     return rec

@@ -28,6 +28,8 @@ _SIGNATURES = {
                            _P], C.c_int),
     "s3cfm_op_linear": ([_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, C.c_int32,
                          _P, _P, C.c_int32, C.POINTER(C.c_float), _P], C.c_int),
+    "s3cfm_op_linear_split": ([_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, C.c_int32,
+                               _P, _P, C.c_int32, C.POINTER(C.c_float), _P], C.c_int),
     "s3cfm_op_attention": ([_P, _P, C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int32, _P, C.c_int32, C.POINTER(C.c_float), _P], C.c_int),
     "s3cfm_op_attention_split": ([_P, _P, C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int32, _P, C.c_int32, C.POINTER(C.c_float),
                                   C.POINTER(C.c_float), _P], C.c_int),
@@ -65,7 +67,7 @@ class CausalConditionalCFM:
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], max_frames: int = 3000, device: int = 0,
                  inference_cfg_rate: float = CW.CFG_RATE, generator: Optional[torch.Generator] = None, max_batch: int = 1,
-                 split_bf16: bool = False):
+                 split_bf16=False):
         self._lib = _lib()
         self.device = torch.device("cuda", device)
         self.max_frames = max_frames
@@ -86,14 +88,17 @@ class CausalConditionalCFM:
             check(self._lib, self._lib.s3cfm_finalize(h))
             self.split_bf16 = False
             if split_bf16:
-                self.set_split_bf16(True)
+                self.set_split_bf16(split_bf16)
         except Exception:
             self.shutdown()
             raise
 
-    def set_split_bf16(self, on: bool) -> None:
-        check(self._lib, self._lib.s3cfm_set_split_bf16(self._h, int(bool(on))))
-        self.split_bf16 = bool(on)
+    def set_split_bf16(self, on) -> None:
+        """False / 0: fp32 matrix instruction everywhere; True / 1: attention on split-bf16 operands; 2: the linear layers and
+        convolutions as well."""
+        mode = int(on) if not isinstance(on, bool) else int(on)
+        check(self._lib, self._lib.s3cfm_set_split_bf16(self._h, mode))
+        self.split_bf16 = on if mode else False
 
     def _check_len(self, L: int) -> None:
         if L < 1 or L > self.max_frames:
@@ -196,8 +201,8 @@ class CausalConditionalCFM:
 
 
 def linear_op(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, pad: int = 0, gelu: bool = False, res: Optional[torch.Tensor] = None,
-              v_from: Optional[int] = None, iters: int = 0, ln: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
-    """``s3cfm_op_linear`` on x [2, Cin, L] (a CUDA tensor; its row stride is the ld the kernel sees), w [Cout, Cin, K] and
+              v_from: Optional[int] = None, iters: int = 0, ln: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, split: bool = False):
+    """``s3cfm_op_linear`` (``split``: ``s3cfm_op_linear_split``, products on split-bf16 operands) on x [2, Cin, L] (a CUDA tensor; its row stride is the ld the kernel sees), w [Cout, Cin, K] and
     bias [Cout] (CPU): returns (y [2, Cout or v_from, L], vt [2, L, 512] or None, average microseconds of `iters` launches)."""
     lib = _lib()
     assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.shape[0] == 2 and x.stride(2) == 1
@@ -216,7 +221,8 @@ def linear_op(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, pad: int = 0
     gamma = beta = None
     if ln is not None:                                       # (gain, shift) of a LayerNorm over the input channels, folded into the layer
         gamma, beta = (t.detach().to("cpu", torch.float32).contiguous() for t in ln)
-    check(lib, lib.s3cfm_op_linear(_ptr(x), Cin, L, ld, C.c_void_p(w.data_ptr()), C.c_void_p(bias.data_ptr()), Cout, K, pad, int(gelu),
+    fn = lib.s3cfm_op_linear_split if split else lib.s3cfm_op_linear
+    check(lib, fn(_ptr(x), Cin, L, ld, C.c_void_p(w.data_ptr()), C.c_void_p(bias.data_ptr()), Cout, K, pad, int(gelu),
                                    _ptr(r_full) if res is not None else None, _ptr(y_full), _ptr(vt_full) if vt_full is not None else None,
                                    v_from or 0, C.c_void_p(gamma.data_ptr()) if ln is not None else None,
                                    C.c_void_p(beta.data_ptr()) if ln is not None else None, iters, C.byref(us), _stream_ptr(x.device)))

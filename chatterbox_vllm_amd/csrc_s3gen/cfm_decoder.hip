@@ -120,11 +120,15 @@ __global__ __launch_bounds__(256) void gemv_kernel(const float* __restrict__ W, 
 // global loads the address arithmetic was a third of the loop's vector instructions).  The wave index is taken through
 // readfirstlane so that the compiler knows what depends on it is uniform.
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
 }
 __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ u32x4 buf_load4u(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
 }
 __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
@@ -306,7 +310,10 @@ __global__ __launch_bounds__(256) void attn_kernel(
 // in LDS.  KSPLIT = 2, 4 or 8: the waves of a workgroup split the reduction over (tap, ci) in contiguous parts and their
 // partial sums meet in LDS in wave order (8 waves when the launch has under two workgroups per CU; 2 parts x 2 frame tiles
 // when it has plenty); KSPLIT = 1: four waves take four neighbouring 32-frame tiles instead.
-template <int KSPLIT, int MB, int OUT_ACT, bool LN_IN>
+// SPLIT: the products on split-bf16 operands (cfm_split.h): a step covers 16 input channels instead of 8, the weights come
+// as three bf16 planes (LinArgs::wsp), the lane's eight x values are split in registers, six matrix instructions per block of
+// 32 channels and step instead of eight twice as long ones; same accumulator layout, so the epilogue is the same.
+template <int KSPLIT, int MB, int OUT_ACT, bool LN_IN, bool SPLIT = false>
 __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void lin_kernel(
         // Leading plain arguments reach the waves in SGPRs set up at wave launch (the library is built with kernel-argument
         // preloading, which takes no struct): the fields of LinArgs that the first addresses are made of, passed a second time.
@@ -315,7 +322,7 @@ __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void lin_kernel(
     LinArgs a = a_;
     a.x = lead_x; a.wt = lead_wt; a.x_bs = lead_x_bs; a.x_ld = lead_x_ld; a.Cin = lead_Cin; a.CoutPad = lead_CoutPad; a.K = lead_K;
     a.L = lead_L; a.pad = lead_pad; a.Cout = lead_Cout;
-    constexpr int PF = 4;
+    constexpr int PF = SPLIT ? 2 : 4;                          // steps of operands in flight (a split step holds twice the channels)
     constexpr int RW = 16 * MB;                                // accumulator rows per lane: MB blocks of 32 channels per wave
     static_assert(MB == 2 || (MB == 1 && KSPLIT <= 4), "one block per wave needs at least four rows per wave to finish");
     __shared__ float part[KSPLIT > 1 ? (KSPLIT == 8 ? 8 : 4) * RW * 64 : 1];
@@ -325,15 +332,19 @@ __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void lin_kernel(
     const int kpart = w % KSPLIT, ntile = w / KSPLIT;          // which part of the reduction, which 32-frame tile
     const int n = (blockIdx.x * NTW + ntile) * 32 + (lane & 31);
     const int cb0 = blockIdx.y * MB, z = blockIdx.z;
-    const int g8 = a.Cin / 8, steps = a.K * g8;
+    constexpr int CH = SPLIT ? 16 : 8;                         // input channels per step
+    constexpr unsigned WSTEP = SPLIT ? 3072u : 1024u;          // weight bytes per step and block of 32 channels
+    const int g8 = a.Cin / CH, steps = a.K * g8;
     const int ns = steps / KSPLIT, s0 = kpart * ns;
     const bool live1 = MB == 2 && (cb0 + 1) * 32 < a.CoutPad;
-    const __amdgpu_buffer_rsrc_t wr_ = make_rsrc(a.wt, (unsigned)(a.CoutPad / 32) * steps * 1024u);
-    const unsigned w0s = (unsigned)cb0 * steps * 1024u;       // this workgroup's first block of 32 channels
+    const __amdgpu_buffer_rsrc_t wr_ = make_rsrc(SPLIT ? static_cast<const void*>(a_.wsp) : static_cast<const void*>(a.wt),
+                                                 (unsigned)(a.CoutPad / 32) * steps * WSTEP);
+    const unsigned w0s = (unsigned)cb0 * steps * WSTEP;       // this workgroup's first block of 32 channels
     const __amdgpu_buffer_rsrc_t xr_ = make_rsrc(a.x + z * a.x_bs, (unsigned)a.Cin * a.x_ld * 4u);
-    const unsigned w1d = live1 ? (unsigned)steps * 1024u : 0u;
-    const unsigned wlane = (unsigned)lane * 16u, xlane = (unsigned)(half * a.x_ld + n) * 4u;
-    const unsigned xrow2 = (unsigned)a.x_ld * 8u;              // bytes between channels 2 j and 2 j + 2
+    const unsigned w1d = live1 ? (unsigned)steps * WSTEP : 0u;
+    // fp32 form: a lane's four x values of a step are channels 8 g + 2 j + half; split form: its eight are 16 g + 8 half + j
+    const unsigned wlane = (unsigned)lane * 16u, xlane = (unsigned)((SPLIT ? 8 : 1) * half * a.x_ld + n) * 4u;
+    const unsigned xrow2 = (unsigned)a.x_ld * (SPLIT ? 4u : 8u);  // bytes between two consecutive x values of a lane
 
     // The rows this wave will finish (NG groups of four accumulator rows), their biases and residual values: loaded
     // first, so that the round trip runs under the main loop instead of after it.
@@ -357,21 +368,31 @@ __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void lin_kernel(
         }
     }
     __builtin_amdgcn_sched_barrier(0);
-    f32x4 A0[PF], A1[PF];
-    float B[PF][4];
+    constexpr int NB = SPLIT ? 8 : 4;                          // x values of a lane per step
+    f32x4 A0[SPLIT ? 1 : PF], A1[SPLIT ? 1 : PF];
+    u32x4 S0[SPLIT ? PF : 1][3], S1[SPLIT ? PF : 1][3];        // split form: three planes per block of 32 channels
+    float B[PF][NB];
     bool okb[PF];
     // Loads are unconditional (a step past the end re-reads the last one, a frame outside [0, L) reads frame 0 of the row) and the
     // zeroing happens when the value is used: a select right after the load would make the wave wait for it at once.
     auto load = [&](int slot, int s) {                         // s: step index of this wave, (tap, g) = divmod(s0 + s, g8)
         const int sg = s0 + (s < ns ? s : ns - 1), tap = sg / g8, g = sg - tap * g8;
-        A0[slot] = buf_load4(wr_, wlane, w0s + (unsigned)sg * 1024u);
-        if constexpr (MB == 2) A1[slot] = buf_load4(wr_, wlane, w0s + (unsigned)sg * 1024u + w1d);
+        if constexpr (SPLIT) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                S0[slot][pl] = buf_load4u(wr_, wlane, w0s + (unsigned)sg * WSTEP + pl * 1024u);
+                if constexpr (MB == 2) S1[slot][pl] = buf_load4u(wr_, wlane, w0s + (unsigned)sg * WSTEP + pl * 1024u + w1d);
+            }
+        } else {
+            A0[slot] = buf_load4(wr_, wlane, w0s + (unsigned)sg * 1024u);
+            if constexpr (MB == 2) A1[slot] = buf_load4(wr_, wlane, w0s + (unsigned)sg * 1024u + w1d);
+        }
         const int col = n + tap - a.pad;
         const bool ok = col >= 0 && col < a.L;
         okb[slot] = ok && s < ns;
-        const unsigned off = ok ? xlane + (unsigned)((tap - a.pad) * 4) : (unsigned)(half * a.x_ld) * 4u;
+        const unsigned off = ok ? xlane + (unsigned)((tap - a.pad) * 4) : (unsigned)((SPLIT ? 8 : 1) * half * a.x_ld) * 4u;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) B[slot][j] = buf_load(xr_, off, (unsigned)(g * 4 + j) * xrow2);
+        for (int j = 0; j < NB; ++j) B[slot][j] = buf_load(xr_, off, (unsigned)(g * (SPLIT ? 16 : 4) + j) * xrow2);
     };
     f32x16 acc0, acc1;
 #pragma unroll
@@ -385,12 +406,33 @@ __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void lin_kernel(
     for (int s = 0; s < ns; s += PF) {
 #pragma unroll
         for (int i = 0; i < PF; ++i) {
+            if constexpr (SPLIT) {
+                u32x4 P[3];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float b0 = okb[i] ? B[i][2 * q] : 0.f, b1 = okb[i] ? B[i][2 * q + 1] : 0.f;
+                    if constexpr (LN_IN) { ln_s1 += b0 + b1; ln_s2 = fmaf(b0, b0, fmaf(b1, b1, ln_s2)); }
+                    unsigned p0, p1, p2;
+                    split_pair(b0, b1, p0, p1, p2);
+                    P[0][q] = p0; P[1][q] = p1; P[2][q] = p2;
+                }
+                constexpr int ta[6] = {0, 2, 1, 0, 1, 0}, tb[6] = {2, 0, 1, 1, 0, 0};   // small partial products first
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, S0[i][ta[k]]),
+                                                                   __builtin_bit_cast(bf16x8_t, P[tb[k]]), acc0, 0, 0, 0);
+                    if constexpr (MB == 2)
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, S1[i][ta[k]]),
+                                                                       __builtin_bit_cast(bf16x8_t, P[tb[k]]), acc1, 0, 0, 0);
+                }
+            } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float bv = okb[i] ? B[i][j] : 0.f;
                 if constexpr (LN_IN) { ln_s1 += bv; ln_s2 = fmaf(bv, bv, ln_s2); }
                 acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[i][j], bv, acc0, 0, 0, 0);
                 if constexpr (MB == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[i][j], bv, acc1, 0, 0, 0);
+            }
             }
             __builtin_amdgcn_sched_barrier(0);                 // keep the refill of this slot here, PF steps ahead of its use
             load(i, s + i + PF);
@@ -505,6 +547,30 @@ __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void lin_kernel(
     }
 }
 
+// Weights in lin_kernel's fp32 tile order -> three bf16 planes in the operand order of v_mfma_f32_32x32x16_bf16:
+//   dst[(((cb * steps16 + tap * (Cin / 16) + g) * 3 + plane) * 64 + lane) * 8 + j] = plane of W[cb * 32 + lane % 32][16 g + 8 (lane / 32) + j][tap]
+// one thread per (block, step, lane)
+__global__ void split_weights_kernel(const float* __restrict__ wt, unsigned short* __restrict__ dst, int nblocks, int K, int Cin) {
+    const int g16n = Cin / 16, g8n = Cin / 8, steps16 = K * g16n;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)nblocks * steps16 * 64) return;
+    const int lane = (int)(idx & 63), sg = (int)((idx >> 6) % steps16), cb = (int)((idx >> 6) / steps16);
+    const int tap = sg / g16n, g = sg - tap * g16n, co = lane & 31, hh = lane >> 5;
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        // channel 16 g + 8 hh + j sits in fp32 group 2 g + hh at element j / 2 of source lane (j % 2) * 32 + co
+        const size_t src = ((((size_t)cb * K + tap) * g8n + (2 * g + hh)) * 64 + (j & 1) * 32 + co) * 4 + (j >> 1);
+        x[j] = wt[src];
+    }
+    unsigned p[3][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) split_pair(x[2 * q], x[2 * q + 1], p[0][q], p[1][q], p[2][q]);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+        *reinterpret_cast<u32x4*>(dst + ((((size_t)cb * steps16 + sg) * 3 + pl) * 64 + lane) * 8) = u32x4{p[pl][0], p[pl][1], p[pl][2], p[pl][3]};
+}
+
 // The estimator's input (decoder.py:254-260): rows 0..79 x, 80..159 mu, 160..239 the speaker vector on every frame,
 // 240..319 cond.  uncond_odd: rows 2 u and 2 u + 1 are the two calls of solve_euler for utterance u (flow_matching.py:105-118):
 // the odd row takes the same x and zeros for the rest; otherwise the four inputs hold one row per row of the launch.
@@ -557,7 +623,7 @@ __global__ void unpack_output_kernel(const float* __restrict__ d, size_t d_bs, i
 // ---- host side ---------------------------------------------------------------------------------------------------
 
 struct Host { std::vector<float> v; std::vector<int64_t> shape; };
-struct Lin { float* wt = nullptr; float* bias = nullptr; int Cin = 0, Cout = 0, K = 1; };
+struct Lin { float* wt = nullptr; float* bias = nullptr; int Cin = 0, Cout = 0, K = 1; unsigned short* wsp = nullptr; };   // wsp: split planes, built on demand
 struct Norm { float* g = nullptr; float* b = nullptr; };
 struct Resnet { Lin conv1, conv2, res; Norm n1, n2; };
 struct Transformer { Lin qkv, out, w1, w2; float *qkv_rsum = nullptr, *w1_rsum = nullptr; };   // norm1 / norm3 folded into qkv / w1
@@ -580,6 +646,7 @@ struct s3cfm {
     float *IN = nullptr, *X = nullptr, *Y = nullptr, *Z = nullptr, *CAT = nullptr, *QK = nullptr, *VT = nullptr, *O = nullptr, *H = nullptr,
           *D = nullptr;
     bool split = false;                                        // attention on split-bf16 operands (s3cfm_set_split_bf16)
+    bool split_lin = false;                                    // the linear layers and convolutions too (mode 2)
     unsigned short *QP = nullptr, *KP = nullptr, *VP = nullptr;     // its operand tensors (cfm_split.h), allocated on first use
 };
 
@@ -683,12 +750,29 @@ int launch_lin(const LinArgs& a, int out_act, int rows, hipStream_t st) {
         else if (out_act == OUT_LRELU) hipLaunchKernelGGL((lin_kernel<KS, MB, OUT_LRELU, false>), grid, block, 0, st, LIN_LEAD(a), a);     \
         else hipLaunchKernelGGL((lin_kernel<KS, MB, OUT_NONE, false>), grid, block, 0, st, LIN_LEAD(a), a);                                \
     } while (0)
+    // split-bf16 operands when the planes exist, the layer is one of the decoder's forms and the 16-channel steps divide
+    // evenly among the parts of the reduction
+    const bool split = a.wsp && (a.K * (a.Cin / 16)) % ks == 0 && (out_act == OUT_NONE || (out_act == OUT_GELU && a.rsum));
+#define S3_LIN_LAUNCH_SPLIT(KS, MB)                                                                                       \
+    do {                                                                                                                  \
+        if (a.rsum && out_act == OUT_GELU) hipLaunchKernelGGL((lin_kernel<KS, MB, OUT_GELU, true, true>), grid, block, 0, st, LIN_LEAD(a), a);  \
+        else if (a.rsum) hipLaunchKernelGGL((lin_kernel<KS, MB, OUT_NONE, true, true>), grid, block, 0, st, LIN_LEAD(a), a);                    \
+        else hipLaunchKernelGGL((lin_kernel<KS, MB, OUT_NONE, false, true>), grid, block, 0, st, LIN_LEAD(a), a);                               \
+    } while (0)
+    if (split) {
+        if (blocks == 1) S3_LIN_LAUNCH_SPLIT(4, 1);
+        else if (ks == 8) S3_LIN_LAUNCH_SPLIT(8, 2);
+        else if (ks == 4) S3_LIN_LAUNCH_SPLIT(4, 2);
+        else if (ks == 2) S3_LIN_LAUNCH_SPLIT(2, 2);
+        else S3_LIN_LAUNCH_SPLIT(1, 2);
+    } else
     if (blocks == 1) S3_LIN_LAUNCH(4, 1);
     else if (ks == 8) S3_LIN_LAUNCH(8, 2);
     else if (ks == 4) S3_LIN_LAUNCH(4, 2);
     else if (ks == 2) S3_LIN_LAUNCH(2, 2);
     else S3_LIN_LAUNCH(1, 2);
 #undef S3_LIN_LAUNCH
+#undef S3_LIN_LAUNCH_SPLIT
 #undef LIN_LEAD
     S3_HIP_CHECK(hipGetLastError());
     return 0;
@@ -731,6 +815,7 @@ int run_lin(const s3cfm* h, const Lin& l, const float* x, int x_rows, float* y, 
     a.Cin = l.Cin; a.Cout = l.Cout; a.CoutPad = (l.Cout + 31) / 32 * 32; a.K = l.K; a.pad = pad; a.L = L;
     a.rsum = rsum; a.ln_eps = 1e-5f;
     if (to_planes) { a.qp = h->QP; a.kp = h->KP; a.vp = h->VP; a.p_ld = h->ld; a.q_scale = kQScale; }
+    if (h->split_lin) a.wsp = l.wsp;
     return launch_lin(a, out_act, h->rows, st);
 }
 
@@ -935,7 +1020,28 @@ extern "C" int s3cfm_set_split_bf16(s3cfm* h, int32_t on) {
         }
         S3_HIP_CHECK(hipDeviceSynchronize());
     }
+    if (on >= 2 && !h->final_proj.wsp) {
+        // every layer's weights once more as bf16 planes, made on the GPU from the fp32 tile order already there
+        std::vector<Lin*> lins = {&h->final_conv, &h->final_proj};
+        for (Stage& sg : h->stages) {
+            lins.insert(lins.end(), {&sg.res.conv1, &sg.res.conv2, &sg.res.res});
+            for (Transformer& tf : sg.tf) lins.insert(lins.end(), {&tf.qkv, &tf.out, &tf.w1, &tf.w2});
+            if (sg.has_tail) lins.push_back(&sg.tail);
+        }
+        for (Lin* l : lins) {
+            const int nblocks = (l->Cout + 31) / 32, steps16 = l->K * (l->Cin / 16);
+            const size_t n = (size_t)nblocks * steps16 * 3 * 512;              // bf16 elements
+            S3_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&l->wsp), n * sizeof(unsigned short)));
+            h->owned.push_back(l->wsp);
+            const long long threads = (long long)nblocks * steps16 * 64;
+            hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, nullptr, l->wt, l->wsp, nblocks,
+                               l->K, l->Cin);
+            S3_HIP_CHECK(hipGetLastError());
+        }
+        S3_HIP_CHECK(hipDeviceSynchronize());
+    }
     h->split = on != 0;
+    h->split_lin = on >= 2;
     return 0;
 }
 
@@ -1023,9 +1129,9 @@ int time_launches(int iters, hipStream_t st, float* avg_us, const std::function<
 }
 }  // namespace
 
-extern "C" int s3cfm_op_linear(const float* x_dev, int32_t Cin, int32_t L, int32_t ld, const float* w_host, const float* bias_host, int32_t Cout,
-                               int32_t K, int32_t pad, int32_t gelu, const float* res_dev, float* y_dev, float* yt_dev, int32_t yt_from,
-                               const float* ln_gamma_host, const float* ln_beta_host, int32_t iters, float* avg_us, void* stream) {
+static int op_linear(const float* x_dev, int32_t Cin, int32_t L, int32_t ld, const float* w_host, const float* bias_host, int32_t Cout,
+                     int32_t K, int32_t pad, int32_t gelu, const float* res_dev, float* y_dev, float* yt_dev, int32_t yt_from,
+                     const float* ln_gamma_host, const float* ln_beta_host, int32_t iters, float* avg_us, void* stream, bool split) {
     S3_REQUIRE(x_dev && w_host && bias_host && y_dev && Cin >= 64 && Cout >= 1 && K >= 1 && L >= 1 && ld >= L && iters >= 0, "bad arguments");
     S3_REQUIRE(!yt_dev || (yt_from % 32 == 0 && Cout - yt_from == kInner), "the frame-major part must be the last 512 channels");
     S3_REQUIRE(!ln_gamma_host == !ln_beta_host && (!ln_gamma_host || K == 1), "a folded LayerNorm needs gain and shift and a one-tap layer");
@@ -1058,9 +1164,34 @@ extern "C" int s3cfm_op_linear(const float* x_dev, int32_t Cin, int32_t L, int32
     a.yt = yt_dev; a.yt_bs = (size_t)ld * kVtLd; a.yt_ld = kVtLd; a.yt_from = yt_from;
     a.Cin = Cin; a.Cout = Cout; a.CoutPad = (Cout + 31) / 32 * 32; a.K = K; a.pad = pad; a.L = L;
     a.rsum = ln_gamma_host ? rsum.p : nullptr; a.ln_eps = 1e-5f;
+    DevBuf wsp;
+    if (split) {
+        const int nblocks = (Cout + 31) / 32, steps16 = K * (Cin / 16);
+        if (wsp.alloc(((size_t)nblocks * steps16 * 3 * 512 + 1) / 2)) return 1;        // bf16 elements in a float buffer
+        const long long threads = (long long)nblocks * steps16 * 64;
+        hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, wt.p,
+                           reinterpret_cast<unsigned short*>(wsp.p), nblocks, K, Cin);
+        S3_HIP_CHECK(hipGetLastError());
+        a.wsp = reinterpret_cast<unsigned short*>(wsp.p);
+    }
     const int rc = time_launches(iters, st, avg_us, [&]() { return launch_lin(a, gelu ? OUT_GELU : OUT_NONE, kRows, st); });
     S3_HIP_CHECK(hipStreamSynchronize(st));
     return rc;
+}
+
+extern "C" int s3cfm_op_linear(const float* x_dev, int32_t Cin, int32_t L, int32_t ld, const float* w_host, const float* bias_host, int32_t Cout,
+                               int32_t K, int32_t pad, int32_t gelu, const float* res_dev, float* y_dev, float* yt_dev, int32_t yt_from,
+                               const float* ln_gamma_host, const float* ln_beta_host, int32_t iters, float* avg_us, void* stream) {
+    return op_linear(x_dev, Cin, L, ld, w_host, bias_host, Cout, K, pad, gelu, res_dev, y_dev, yt_dev, yt_from, ln_gamma_host, ln_beta_host,
+                     iters, avg_us, stream, false);
+}
+
+extern "C" int s3cfm_op_linear_split(const float* x_dev, int32_t Cin, int32_t L, int32_t ld, const float* w_host, const float* bias_host,
+                                     int32_t Cout, int32_t K, int32_t pad, int32_t gelu, const float* res_dev, float* y_dev, float* yt_dev,
+                                     int32_t yt_from, const float* ln_gamma_host, const float* ln_beta_host, int32_t iters, float* avg_us,
+                                     void* stream) {
+    return op_linear(x_dev, Cin, L, ld, w_host, bias_host, Cout, K, pad, gelu, res_dev, y_dev, yt_dev, yt_from, ln_gamma_host, ln_beta_host,
+                     iters, avg_us, stream, true);
 }
 
 extern "C" int s3cfm_op_attention(const float* qk_dev, const float* vt_dev, int32_t n_utt, const int32_t* keys, int32_t L, int32_t ld,

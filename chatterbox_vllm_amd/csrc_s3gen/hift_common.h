@@ -89,6 +89,10 @@ struct LinArgs {
     // qp not null (a q | k | v projection of 3 x 512 channels, 8 heads x 64): nothing goes to y / yt; the outputs are written
     // as split-bf16 attention operands instead (cfm_split.h: q scaled by q_scale, three planes each), p_ld = their row stride
     unsigned short *qp, *kp, *vp; int p_ld; float q_scale;
+    // wsp not null: the weights as three bf16 planes in the operand order of the bf16 matrix instruction (cfm_decoder.hip:
+    // split_weights_kernel), and the products taken on split operands (cfm_split.h); needs K * Cin / 16 steps to divide by the
+    // launch's reduction split, which launch_lin checks (it falls back to wt otherwise)
+    const unsigned short* wsp;
 };
 enum { OUT_NONE = 0, OUT_GELU = 1, OUT_SWISH = 2, OUT_LRELU = 3 };   // OUT_LRELU: slope 0.01
 int launch_lin(const LinArgs& a, int out_act, int rows, hipStream_t st);

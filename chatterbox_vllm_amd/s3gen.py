@@ -36,12 +36,13 @@ S3GEN_SR = 24000
 class S3Token2Wav:
     def __init__(self, flow_state_dict: Dict[str, torch.Tensor], mel2wav_state_dict: Dict[str, torch.Tensor],
                  decoder: Optional[Callable] = None, max_tokens: int = 1500, device: int = 0, max_batch: int = 1,
-                 chains: int = 1, split_bf16: bool = False):
+                 chains: int = 1, split_bf16=False):
         self.device = torch.device("cuda", device)
         self.encoder = FlowEncoder(flow_state_dict, max_tokens=max_tokens, device=device)
         self.mel2wav = HiFTGenerator(mel2wav_state_dict, max_batch=1, max_frames=2 * max_tokens, device=device)
         self._own_decoder = decoder is None
-        # split_bf16: the decoder's attention launches on bf16 triples (CausalConditionalCFM; off = the fp32 matrix instruction)
+        # split_bf16: 1 / True = the decoder's attention launches on bf16 triples, 2 = its linear layers and convolutions too
+        # (CausalConditionalCFM; 0 / False = the fp32 matrix instruction)
         self.decoder = (CausalConditionalCFM(flow_state_dict, max_frames=2 * max_tokens, device=device, max_batch=max_batch,
                                              split_bf16=split_bf16)
                         if decoder is None else decoder)

@@ -62,6 +62,13 @@ def postprocess_speech_ids(token_ids: Sequence[int], prompt: str = "", tail_crop
     return torch.tensor(ids, dtype=torch.int64)
 
 
+def _s3gen_split_mode() -> int:
+    """CHATTERBOX_S3GEN_SPLIT_BF16: 0 / unset = the flow-matching decoder's matrix launches on the fp32 matrix instruction (the
+    reference's arithmetic); 1 = its attention on split-bf16 operands; 2 = its linear layers and convolutions too."""
+    v = os.environ.get("CHATTERBOX_S3GEN_SPLIT_BF16", "0").strip().lower()
+    return {"": 0, "0": 0, "false": 0, "off": 0, "1": 1, "true": 1, "on": 1, "yes": 1, "2": 2}.get(v, 0)
+
+
 def _env_ms(name: str, default: str, sr: int) -> int:
     """An environment variable holding whole milliseconds, as samples at `sr`."""
     return int(sr * int(os.environ.get(name, default)) / 1000)
@@ -181,7 +188,7 @@ class ChatterboxTTS:
             kwargs["s3gen"] = S3Token2Wav({k[len("flow."):]: v for k, v in s3_sd.items() if k.startswith("flow.")},
                                           {k[len("mel2wav."):]: v for k, v in s3_sd.items() if k.startswith("mel2wav.")},
                                           max_batch=min(4, max(1, max_batch_size)), chains=2,
-                                          split_bf16=_env_flag("CHATTERBOX_S3GEN_SPLIT_BF16"))
+                                          split_bf16=_s3gen_split_mode())
         cfg = cls.variant_config(variant)
         # the backbone's depth is the checkpoint's (30 for the published ones): a cut-down checkpoint loads as what it is
         depth = 1 + max((int(k.split(".")[2]) for k in sd if k.startswith("tfmr.layers.")), default=-1)
@@ -221,7 +228,7 @@ class ChatterboxTTS:
             flow_sd.update(cfm_weights.synthetic_state_dict())
             kwargs["s3gen"] = S3Token2Wav(flow_sd, hift_weights.synthetic_state_dict(), max_tokens=kwargs.get("max_model_len", 1000) + 256,
                                           max_batch=min(4, max(1, kwargs.get("max_batch_size", 10))), chains=2,
-                                          split_bf16=_env_flag("CHATTERBOX_S3GEN_SPLIT_BF16"))
+                                          split_bf16=_s3gen_split_mode())
         cfg = cls.variant_config(variant)
         if n_layers is not None:
             cfg = T3ModelConfig(n_layers=n_layers, text_vocab=cfg.text_vocab)

@@ -38,11 +38,12 @@ int s3cfm_destroy(s3cfm* h);
 int s3cfm_load_tensor(s3cfm* h, const char* name, const float* host_data, const int64_t* shape, int32_t ndim);
 int s3cfm_finalize(s3cfm* h);
 
-/* Arithmetic of the attention launches (no counterpart in the reference, which computes in fp32): on = 0, the default, takes
- * every product on the fp32 matrix instruction; on = 1 holds each fp32 operand as three bf16 values whose sum is the operand
- * and takes six partial products per product on the bf16 matrix instruction with fp32 accumulation (what is left out is
- * below 2^-24 of a product, so results stay as close to fp64 as the fp32 form's; the launch is 1.7x shorter at 1 000 frames).
- * Allocates 9 KiB of workspace per frame and utterance on first use; synchronises the device. */
+/* Arithmetic of the matrix launches (no counterpart in the reference, which computes in fp32): on = 0, the default, takes
+ * every product on the fp32 matrix instruction; on = 1 holds each fp32 operand of the attention launches as three bf16 values
+ * whose sum is the operand and takes six partial products per product on the bf16 matrix instruction with fp32 accumulation
+ * (what is left out is below 2^-24 of a product, so results stay as close to fp64 as the fp32 form's; the launch is 1.9x
+ * shorter at 1 000 frames); on = 2 does the same in the linear layers and convolutions as well.  Allocates 9 KiB of workspace
+ * per frame and utterance on first use, and for on = 2 the weights a second time (6 bytes each); synchronises the device. */
 int s3cfm_set_split_bf16(s3cfm* h, int32_t on);
 
 /* One estimator call, `ConditionalDecoder.forward(x, mask, mu, t, spks, cond)` (decoder.py:233-317) on two rows:
@@ -83,6 +84,12 @@ int s3cfm_solve_batch(s3cfm* h, int32_t n_utt, const int32_t* frames, int32_t L,
 int s3cfm_op_linear(const float* x_dev, int32_t Cin, int32_t L, int32_t ld, const float* w_host, const float* bias_host, int32_t Cout,
                     int32_t K, int32_t pad, int32_t gelu, const float* res_dev, float* y_dev, float* yt_dev, int32_t yt_from,
                     const float* ln_gamma_host, const float* ln_beta_host, int32_t iters, float* avg_us, void* stream);
+
+/* s3cfm_op_linear with the products taken on split-bf16 operands (the arithmetic of s3cfm_set_split_bf16 mode 2): weights as
+ * three bf16 planes made on the GPU, the x values split in registers.  Same arguments and results to the same tolerance. */
+int s3cfm_op_linear_split(const float* x_dev, int32_t Cin, int32_t L, int32_t ld, const float* w_host, const float* bias_host, int32_t Cout,
+                          int32_t K, int32_t pad, int32_t gelu, const float* res_dev, float* y_dev, float* yt_dev, int32_t yt_from,
+                          const float* ln_gamma_host, const float* ln_beta_host, int32_t iters, float* avg_us, void* stream);
 
 /* Self-attention of a transformer block (the diffusers default processor as matcha/transformer.py:267-273 calls it: 8 heads x
  * 64, softmax(q k^T / 8) v, every frame attends to every frame): qk_dev [2][1024][ld] (q in channels 0..511, k in 512..1023,

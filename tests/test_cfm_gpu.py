@@ -23,8 +23,9 @@ def sd():
     return CW.synthetic_state_dict()
 
 
-# every test of the decoder runs in both arithmetic forms of the attention launches, to the same tolerances
-_FORMS = dict(params=[False, True], ids=["fp32", "split_bf16"])
+# every test of the decoder runs in all three arithmetic forms (fp32 matrix instruction; attention on split-bf16 operands;
+# attention, linear layers and convolutions on them), to the same tolerances
+_FORMS = dict(params=[False, True, 2], ids=["fp32", "split_bf16_attention", "split_bf16_everywhere"])
 
 
 @pytest.fixture(scope="module", **_FORMS)
@@ -159,9 +160,10 @@ def test_token_to_waveform_chain_with_the_packaged_decoder(sd, split):
     s3.shutdown()
 
 
+@pytest.mark.parametrize("split", [False, True], ids=["fp32", "split_bf16"])
 @pytest.mark.parametrize("Cin,Cout,K,pad,L", [(256, 256, 1, 0, 1000), (320, 256, 3, 2, 77), (1024, 256, 1, 0, 333), (512, 256, 3, 2, 50),
                                                (256, 1024, 1, 0, 1), (256, 80, 1, 0, 97), (256, 1024, 1, 0, 4200), (256, 1024, 1, 0, 1000), (256, 1536, 1, 0, 1000), (1024, 256, 1, 0, 1100)])
-def test_linear_kernel_against_fp64(Cin, Cout, K, pad, L):
+def test_linear_kernel_against_fp64(Cin, Cout, K, pad, L, split):
     """Every shape class the estimator launches: the four workgroup forms (8-, 4- and 2-way split of the reduction, none:
     chosen by the number of tiles; 1100 frames x 256 channels takes one 32-channel block per wave), causal taps, ragged
     lengths, 80 output channels, GELU and the residual add."""
@@ -180,12 +182,13 @@ def test_linear_kernel_against_fp64(Cin, Cout, K, pad, L):
     xd = torch.zeros(2, Cin, ld, device="cuda")
     xd[:, :, L:] = 7.0                                        # columns past L must not be read as data
     xd[:, :, :L] = x.cuda()
-    y, _, _ = linear_op(xd[:, :, :L], w, b, pad=pad, gelu=gelu, res=res.cuda())
+    y, _, _ = linear_op(xd[:, :, :L], w, b, pad=pad, gelu=gelu, res=res.cuda(), split=split)
     assert (y.double().cpu() - want).abs().max().item() < 2e-5
 
 
+@pytest.mark.parametrize("split", [False, True], ids=["fp32", "split_bf16"])
 @pytest.mark.parametrize("Cout,L,offset", [(1536, 1000, 0.0), (1024, 333, 3.0), (1024, 4200, -1.0), (256, 40, 0.5)])
-def test_linear_kernel_with_the_layer_norm_folded_in(Cout, L, offset):
+def test_linear_kernel_with_the_layer_norm_folded_in(Cout, L, offset, split):
     """norm1 / norm3 of a transformer block ride in the layer that consumes them (LinArgs::rsum): W LayerNorm(x) + b against
     fp64, with channel means away from zero (the folded form subtracts mean * row-sum after the product), for every
     workgroup form, with GELU and with the frame-major part."""
@@ -204,14 +207,15 @@ def test_linear_kernel_with_the_layer_norm_folded_in(Cout, L, offset):
     ld = (L + 63) // 64 * 64 + 64
     xd = torch.zeros(2, 256, ld, device="cuda")
     xd[:, :, :L] = x.cuda()
-    y, vt, _ = linear_op(xd[:, :, :L], w, b, gelu=gelu, v_from=1024 if Cout == 1536 else None, ln=(gamma, beta))
+    y, vt, _ = linear_op(xd[:, :, :L], w, b, gelu=gelu, v_from=1024 if Cout == 1536 else None, ln=(gamma, beta), split=split)
     if Cout == 1536:
         assert (vt.double().cpu() - want[:, 1024:].transpose(1, 2)).abs().max().item() < 2e-5
         want = want[:, :1024]
     assert (y.double().cpu() - want).abs().max().item() < 2e-5
 
 
-def test_qkv_projection_writes_v_frame_major():
+@pytest.mark.parametrize("split", [False, True], ids=["fp32", "split_bf16"])
+def test_qkv_projection_writes_v_frame_major(split):
     from chatterbox_vllm_amd.cfm_decoder import linear_op
     L = 210
     g = torch.Generator().manual_seed(2)
@@ -220,7 +224,7 @@ def test_qkv_projection_writes_v_frame_major():
     want = torch.nn.functional.conv1d(x.double(), w.double())
     xd = torch.zeros(2, 256, 320, device="cuda")
     xd[:, :, :L] = x.cuda()
-    y, vt, _ = linear_op(xd[:, :, :L], w, torch.zeros(1536), v_from=1024)
+    y, vt, _ = linear_op(xd[:, :, :L], w, torch.zeros(1536), v_from=1024, split=split)
     assert y.shape == (2, 1024, L) and vt.shape == (2, L, 512)
     assert (y.double().cpu() - want[:, :1024]).abs().max().item() < 1e-5
     assert (vt.double().cpu() - want[:, 1024:].transpose(1, 2)).abs().max().item() < 1e-5

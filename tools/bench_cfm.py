@@ -13,7 +13,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--frames", type=int, nargs="+", default=[1000])
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--iters", type=int, default=3)
-ap.add_argument("--split-bf16", action="store_true", help="attention launches on split-bf16 operands")
+ap.add_argument("--split-bf16", type=int, nargs="?", const=1, default=0, help="1: attention launches on split-bf16 operands; 2: linear layers too")
 args = ap.parse_args()
 m = CausalConditionalCFM(CW.synthetic_state_dict(), max_frames=max(args.frames), split_bf16=args.split_bf16)
 for L in args.frames:

@@ -21,7 +21,7 @@ def main():
     ap.add_argument("--batch", type=int, nargs="+", default=[1, 2, 4, 8])
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--ragged", action="store_true", help="utterance u of a batch gets frames * (1 - 0.05 u)")
-    ap.add_argument("--split-bf16", action="store_true", help="attention launches on split-bf16 operands")
+    ap.add_argument("--split-bf16", type=int, nargs="?", const=1, default=0, help="1: attention launches on split-bf16 operands; 2: linear layers too")
     args = ap.parse_args()
     cfm = CausalConditionalCFM(CW.synthetic_state_dict(), max_frames=max(args.frames), max_batch=max(args.batch),
                                split_bf16=args.split_bf16)

@@ -22,6 +22,7 @@ if __name__ == "__main__":
     ap.add_argument("--variants", nargs="+", default=["1x1", "3x1", "1x8", "2x4"], help="<utterances in flight>x<utterances per call>")
     ap.add_argument("--chunks", type=int, default=154)
     args = ap.parse_args()
-    # "2x4" = two chains x four utterances per call; a trailing "s" (as in "2x4s") = attention on split-bf16 operands
-    variants = tuple(tuple(int(v) for v in s.rstrip("s").split("x")) + ((True,) if s.endswith("s") else ()) for s in args.variants)
+    # "2x4" = two chains x four utterances per call; "2x4s" = attention on split-bf16 operands, "2x4ss" = every matrix launch
+    variants = tuple(tuple(int(v) for v in s.rstrip("s").split("x")) + ((len(s) - len(s.rstrip("s")),) if s.endswith("s") else ())
+                     for s in args.variants)
     print(json.dumps(bench.s3gen_job_leg(0, job_lengths(args.chunks), variants=variants), indent=1))

@@ -313,7 +313,10 @@ __global__ __launch_bounds__(256) void attn_kernel(
 // SPLIT: the products on split-bf16 operands (cfm_split.h): a step covers 16 input channels instead of 8, the weights come
 // as three bf16 planes (LinArgs::wsp), the lane's eight x values are split in registers, six matrix instructions per block of
 // 32 channels and step instead of eight twice as long ones; same accumulator layout, so the epilogue is the same.
-template <int KSPLIT, int MB, int OUT_ACT, bool LN_IN, bool SPLIT = false>
+// DEEP: operands of four steps in flight (two in the split form) instead of two (one).  The deep form wins while a launch
+// has few workgroups per CU (under about 1 200 columns: nothing else hides the first loads' latency), the shallow one
+// above that (fewer registers, more waves per SIMD): 68.7 -> 65.6 ms per fp32 solve at 1 000 frames, 37.2 <- 38.7 at 500.
+template <int KSPLIT, int MB, int OUT_ACT, bool LN_IN, bool SPLIT = false, bool DEEP = true>
 __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void lin_kernel(
         // Leading plain arguments reach the waves in SGPRs set up at wave launch (the library is built with kernel-argument
         // preloading, which takes no struct): the fields of LinArgs that the first addresses are made of, passed a second time.
@@ -322,7 +325,7 @@ __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void lin_kernel(
     LinArgs a = a_;
     a.x = lead_x; a.wt = lead_wt; a.x_bs = lead_x_bs; a.x_ld = lead_x_ld; a.Cin = lead_Cin; a.CoutPad = lead_CoutPad; a.K = lead_K;
     a.L = lead_L; a.pad = lead_pad; a.Cout = lead_Cout;
-    constexpr int PF = SPLIT ? 2 : 4;                          // steps of operands in flight (a split step holds twice the channels)
+    constexpr int PF = SPLIT ? (DEEP ? 2 : 1) : (DEEP ? 4 : 2);     // steps of operands in flight (a split step holds twice the channels)
     constexpr int RW = 16 * MB;                                // accumulator rows per lane: MB blocks of 32 channels per wave
     static_assert(MB == 2 || (MB == 1 && KSPLIT <= 4), "one block per wave needs at least four rows per wave to finish");
     __shared__ float part[KSPLIT > 1 ? (KSPLIT == 8 ? 8 : 4) * RW * 64 : 1];
@@ -741,36 +744,37 @@ int launch_lin(const LinArgs& a, int out_act, int rows, hipStream_t st) {
     const int ntw = ks == 8 ? 1 : 4 / ks;
     const dim3 grid((L + 32 * ntw - 1) / (32 * ntw), blocks == 2 ? mb : a.CoutPad / 32, rows), block(ks == 8 ? 512 : 256);
 #define LIN_LEAD(a) (a).x, (a).wt, (a).x_bs, (a).x_ld, (a).Cin, (a).CoutPad, (a).K, (a).L, (a).pad, (a).Cout
-#define S3_LIN_LAUNCH(KS, MB)                                                                                             \
+#define S3_LIN_LAUNCH(KS, MB, DEEP)                                                                                       \
     do {                                                                                                                  \
-        if (a.rsum && out_act == OUT_GELU) hipLaunchKernelGGL((lin_kernel<KS, MB, OUT_GELU, true>), grid, block, 0, st, LIN_LEAD(a), a);   \
-        else if (a.rsum) hipLaunchKernelGGL((lin_kernel<KS, MB, OUT_NONE, true>), grid, block, 0, st, LIN_LEAD(a), a);                     \
-        else if (out_act == OUT_GELU) hipLaunchKernelGGL((lin_kernel<KS, MB, OUT_GELU, false>), grid, block, 0, st, LIN_LEAD(a), a);       \
-        else if (out_act == OUT_SWISH) hipLaunchKernelGGL((lin_kernel<KS, MB, OUT_SWISH, false>), grid, block, 0, st, LIN_LEAD(a), a);     \
-        else if (out_act == OUT_LRELU) hipLaunchKernelGGL((lin_kernel<KS, MB, OUT_LRELU, false>), grid, block, 0, st, LIN_LEAD(a), a);     \
-        else hipLaunchKernelGGL((lin_kernel<KS, MB, OUT_NONE, false>), grid, block, 0, st, LIN_LEAD(a), a);                                \
+        if (a.rsum && out_act == OUT_GELU) hipLaunchKernelGGL((lin_kernel<KS, MB, OUT_GELU, true, false, DEEP>), grid, block, 0, st, LIN_LEAD(a), a);   \
+        else if (a.rsum) hipLaunchKernelGGL((lin_kernel<KS, MB, OUT_NONE, true, false, DEEP>), grid, block, 0, st, LIN_LEAD(a), a);                     \
+        else if (out_act == OUT_GELU) hipLaunchKernelGGL((lin_kernel<KS, MB, OUT_GELU, false, false, DEEP>), grid, block, 0, st, LIN_LEAD(a), a);       \
+        else if (out_act == OUT_SWISH) hipLaunchKernelGGL((lin_kernel<KS, MB, OUT_SWISH, false, false, DEEP>), grid, block, 0, st, LIN_LEAD(a), a);     \
+        else if (out_act == OUT_LRELU) hipLaunchKernelGGL((lin_kernel<KS, MB, OUT_LRELU, false, false, DEEP>), grid, block, 0, st, LIN_LEAD(a), a);     \
+        else hipLaunchKernelGGL((lin_kernel<KS, MB, OUT_NONE, false, false, DEEP>), grid, block, 0, st, LIN_LEAD(a), a);                                \
     } while (0)
     // split-bf16 operands when the planes exist, the layer is one of the decoder's forms and the 16-channel steps divide
     // evenly among the parts of the reduction
     const bool split = a.wsp && (a.K * (a.Cin / 16)) % ks == 0 && (out_act == OUT_NONE || (out_act == OUT_GELU && a.rsum));
-#define S3_LIN_LAUNCH_SPLIT(KS, MB)                                                                                       \
+#define S3_LIN_LAUNCH_SPLIT(KS, MB, DEEP)                                                                                 \
     do {                                                                                                                  \
-        if (a.rsum && out_act == OUT_GELU) hipLaunchKernelGGL((lin_kernel<KS, MB, OUT_GELU, true, true>), grid, block, 0, st, LIN_LEAD(a), a);  \
-        else if (a.rsum) hipLaunchKernelGGL((lin_kernel<KS, MB, OUT_NONE, true, true>), grid, block, 0, st, LIN_LEAD(a), a);                    \
-        else hipLaunchKernelGGL((lin_kernel<KS, MB, OUT_NONE, false, true>), grid, block, 0, st, LIN_LEAD(a), a);                               \
+        if (a.rsum && out_act == OUT_GELU) hipLaunchKernelGGL((lin_kernel<KS, MB, OUT_GELU, true, true, DEEP>), grid, block, 0, st, LIN_LEAD(a), a);  \
+        else if (a.rsum) hipLaunchKernelGGL((lin_kernel<KS, MB, OUT_NONE, true, true, DEEP>), grid, block, 0, st, LIN_LEAD(a), a);                    \
+        else hipLaunchKernelGGL((lin_kernel<KS, MB, OUT_NONE, false, true, DEEP>), grid, block, 0, st, LIN_LEAD(a), a);                               \
     } while (0)
-    if (split) {
-        if (blocks == 1) S3_LIN_LAUNCH_SPLIT(4, 1);
-        else if (ks == 8) S3_LIN_LAUNCH_SPLIT(8, 2);
-        else if (ks == 4) S3_LIN_LAUNCH_SPLIT(4, 2);
-        else if (ks == 2) S3_LIN_LAUNCH_SPLIT(2, 2);
-        else S3_LIN_LAUNCH_SPLIT(1, 2);
-    } else
-    if (blocks == 1) S3_LIN_LAUNCH(4, 1);
-    else if (ks == 8) S3_LIN_LAUNCH(8, 2);
-    else if (ks == 4) S3_LIN_LAUNCH(4, 2);
-    else if (ks == 2) S3_LIN_LAUNCH(2, 2);
-    else S3_LIN_LAUNCH(1, 2);
+#define S3_LIN_FORMS(LAUNCH, DEEP)                                                                                        \
+    do {                                                                                                                  \
+        if (blocks == 1) LAUNCH(4, 1, DEEP);                                                                              \
+        else if (ks == 8) LAUNCH(8, 2, DEEP);                                                                             \
+        else if (ks == 4) LAUNCH(4, 2, DEEP);                                                                             \
+        else if (ks == 2) LAUNCH(2, 2, DEEP);                                                                             \
+        else LAUNCH(1, 2, DEEP);                                                                                          \
+    } while (0)
+    static const int deep_below = getenv("S3CFM_DEEP_BELOW") ? atoi(getenv("S3CFM_DEEP_BELOW")) : 1200;
+    const bool deep = (long long)L * rows < deep_below;        // columns of the launch
+    if (split) { if (deep) S3_LIN_FORMS(S3_LIN_LAUNCH_SPLIT, true); else S3_LIN_FORMS(S3_LIN_LAUNCH_SPLIT, false); }
+    else { if (deep) S3_LIN_FORMS(S3_LIN_LAUNCH, true); else S3_LIN_FORMS(S3_LIN_LAUNCH, false); }
+#undef S3_LIN_FORMS
 #undef S3_LIN_LAUNCH
 #undef S3_LIN_LAUNCH_SPLIT
 #undef LIN_LEAD

@@ -94,7 +94,7 @@ __device__ __forceinline__ float half_sum(float x) {
 // wave's NEXT key tile, the second product of the CURRENT one), without branches, so that the compiler interleaves the two
 // streams.  The key mask is only ever needed on a wave's last tile, which is peeled off the loop.
 template <int QT>
-__global__ __launch_bounds__(256) void attn_split_kernel(const unsigned short* __restrict__ lead_qp, const unsigned short* __restrict__ lead_kp,
+__global__ __launch_bounds__(256, QT == 1 ? 2 : 1) void attn_split_kernel(const unsigned short* __restrict__ lead_qp, const unsigned short* __restrict__ lead_kp,
                                                          const unsigned short* __restrict__ lead_vp, int lead_ld, int lead_L, int lead_rows,
                                                          SplitAttnArgs a_) {
     __shared__ float so[4 * 32 * 64];

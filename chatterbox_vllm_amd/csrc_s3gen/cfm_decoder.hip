@@ -349,16 +349,19 @@ __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void lin_kernel(
     const unsigned wlane = (unsigned)lane * 16u, xlane = (unsigned)((SPLIT ? 8 : 1) * half * a.x_ld + n) * 4u;
     const unsigned xrow2 = (unsigned)a.x_ld * (SPLIT ? 4u : 8u);  // bytes between two consecutive x values of a lane
 
-    // The rows this wave will finish (NG groups of four accumulator rows), their biases and residual values: loaded
-    // first, so that the round trip runs under the main loop instead of after it.
+    // The rows this wave will finish (NG groups of four accumulator rows), their biases and residual values.  Where the
+    // waves split the reduction a wave finishes 4 to 16 rows and asks for these values first, so that the round trip runs
+    // under the main loop instead of after it.  A wave of the whole-reduction form finishes all 32 rows: 64 to 96 values
+    // held through the loop would cost it a wave per SIMD, so it asks after the loop, when the operand registers are free
+    // (those launches are large: other waves cover the round trip).  A layer with a folded LayerNorm has no residual.
     constexpr int NG = RW / KSPLIT / 4;
+    constexpr bool EPI_EARLY = KSPLIT > 1;
     auto rbase = [&](int gi) { return kpart * (RW / KSPLIT) + 4 * gi; };
-    float pbias[NG][4], pres[NG][4], prsum[LN_IN ? NG : 1][4];
-    const bool has_res = a.res != nullptr;
+    float pbias[NG][4], pres[LN_IN ? 1 : NG][4], prsum[LN_IN ? NG : 1][4];
+    const bool has_res = !LN_IN && a.res != nullptr;
     const float* resp = (has_res ? a.res : a.bias) + (has_res ? z * a.y_bs + (size_t)(n < a.L ? n : a.L - 1) : 0);
     const size_t res_ld = has_res ? a.y_ld : 0;
-#pragma unroll
-    for (int gi = 0; gi < NG; ++gi) {
+    auto load_epilogue_operands = [&](int gi) {
         const int cb = cb0 + (rbase(gi) >> 4), co0 = cb * 32 + 8 * ((rbase(gi) & 15) >> 2) + 4 * half;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -366,9 +369,13 @@ __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void lin_kernel(
             // the frame-major rows are never stored with these values
             const int co = co0 + e < a.Cout ? co0 + e : a.Cout - 1;
             pbias[gi][e] = a.bias[co];
-            pres[gi][e] = resp[(has_res && !(a.yt && co >= a.yt_from) ? co : 0) * res_ld];
             if constexpr (LN_IN) prsum[gi][e] = a.rsum[co];
+            else pres[gi][e] = resp[(has_res && !(a.yt && co >= a.yt_from) ? co : 0) * res_ld];
         }
+    };
+    if constexpr (EPI_EARLY) {
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) load_epilogue_operands(gi);
     }
     __builtin_amdgcn_sched_barrier(0);
     constexpr int NB = SPLIT ? 8 : 4;                          // x values of a lane per step
@@ -492,8 +499,9 @@ __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void lin_kernel(
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            if (co0 + e < a.Cout) a.y[z * a.y_bs + (size_t)(co0 + e) * a.y_ld + n] = has_res ? v[e] + pres[gi][e] : v[e];
+            if (co0 + e < a.Cout) a.y[z * a.y_bs + (size_t)(co0 + e) * a.y_ld + n] = has_res ? v[e] + pres[LN_IN ? 0 : gi][e] : v[e];
     };
+
     if constexpr (LN_IN) {                                     // the two halves of a wave hold the two channel parities of a frame
         ln_s1 += __shfl_xor(ln_s1, 32);
         ln_s2 += __shfl_xor(ln_s2, 32);
@@ -540,12 +548,18 @@ __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void lin_kernel(
             ln_mean = ln_s1 * inv_c;
             ln_rstd = 1.0f / sqrtf(fmaxf(ln_s2 * inv_c - ln_mean * ln_mean, 0.f) + a.ln_eps);
         }
+        // the operands of group gi + 1 are requested before group gi is finished: two groups of values live at a time
+        __builtin_amdgcn_sched_barrier(0);
+        load_epilogue_operands(0);
 #pragma unroll
         for (int gi = 0; gi < NG; ++gi) {
+            if (gi + 1 < NG) load_epilogue_operands(gi + 1);
+            __builtin_amdgcn_sched_barrier(0);
             float v[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = gi < 4 ? acc0[4 * gi + e] : acc1[4 * (gi & 3) + e];
             finish4(v, gi);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
@@ -720,8 +734,8 @@ int make_norm(s3cfm* h, Norm* n, const std::string& name) {
 
 int launch_lin(const LinArgs& a, int out_act, int rows, hipStream_t st) {
     S3_REQUIRE(a.Cin % 64 == 0 && a.x != a.y, "linear layer: input channels must be a multiple of 64 and the output a different tensor");
-    S3_REQUIRE(!a.rsum || (a.K == 1 && a.pad == 0 && (out_act == OUT_NONE || out_act == OUT_GELU)),
-               "linear layer: a folded LayerNorm needs a one-tap layer without or with GELU");
+    S3_REQUIRE(!a.rsum || (a.K == 1 && a.pad == 0 && !a.res && (out_act == OUT_NONE || out_act == OUT_GELU)),
+               "linear layer: a folded LayerNorm needs a one-tap layer without or with GELU and without a residual");
     const int L = a.L, mb = (a.CoutPad + 63) / 64;
     // enough 64 x 128 tiles to give every CU several workgroups: no split of the reduction
     static const int wide_min = getenv("S3CFM_WIDE_MIN") ? atoi(getenv("S3CFM_WIDE_MIN")) : 1024;

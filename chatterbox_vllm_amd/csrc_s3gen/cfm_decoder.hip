@@ -120,6 +120,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const float* __restrict__ W, 
 // global loads the address arithmetic was a third of the loop's vector instructions).  The wave index is taken through
 // readfirstlane so that the compiler knows what depends on it is uniform.
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
@@ -316,7 +317,12 @@ __global__ __launch_bounds__(256) void attn_kernel(
 // DEEP: operands of four steps in flight (two in the split form) instead of two (one).  The deep form wins while a launch
 // has few workgroups per CU (under about 1 200 columns: nothing else hides the first loads' latency), the shallow one
 // above that (fewer registers, more waves per SIMD): 68.7 -> 65.6 ms per fp32 solve at 1 000 frames, 37.2 <- 38.7 at 500.
-template <int KSPLIT, int MB, int OUT_ACT, bool LN_IN, bool SPLIT = false, bool DEEP = true>
+// WLDS (split form without a split of the reduction, i.e. the large launches): the four waves of a workgroup need the
+// same weight planes, so the workgroup fetches them once, two steps (12 KiB) at a time, and the waves read them from LDS.
+// In the split form a step's operands are 8 KiB per wave for twelve 32-cycle matrix instructions, and sixteen waves per
+// CU then ask the vector memory path for more bytes per cycle (64 B) than it returns; shared, the weights are 1.5 KiB
+// per wave and step there and 6 KiB from LDS (128 B per cycle).
+template <int KSPLIT, int MB, int OUT_ACT, bool LN_IN, bool SPLIT = false, bool DEEP = true, bool WLDS = false>
 __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void lin_kernel(
         // Leading plain arguments reach the waves in SGPRs set up at wave launch (the library is built with kernel-argument
         // preloading, which takes no struct): the fields of LinArgs that the first addresses are made of, passed a second time.
@@ -328,6 +334,8 @@ __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void lin_kernel(
     constexpr int PF = SPLIT ? (DEEP ? 2 : 1) : (DEEP ? 4 : 2);     // steps of operands in flight (a split step holds twice the channels)
     constexpr int RW = 16 * MB;                                // accumulator rows per lane: MB blocks of 32 channels per wave
     static_assert(MB == 2 || (MB == 1 && KSPLIT <= 4), "one block per wave needs at least four rows per wave to finish");
+    static_assert(!WLDS || (SPLIT && KSPLIT == 1 && MB == 2 && !DEEP), "weights through LDS: the split form's whole-reduction launches");
+    __shared__ u32x4 wls[WLDS ? 2 * 768 : 1];                  // two stages of two steps x two blocks x three planes x 1 KiB
     __shared__ float part[KSPLIT > 1 ? (KSPLIT == 8 ? 8 : 4) * RW * 64 : 1];
     __shared__ float lnst[LN_IN && KSPLIT > 1 ? (KSPLIT == 8 ? 8 : 4) * 2 * 32 : 1];   // per wave and frame: sum, sum of squares
     constexpr int NTW = KSPLIT == 8 ? 1 : 4 / KSPLIT;          // waves of a workgroup along the frames
@@ -385,8 +393,21 @@ __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void lin_kernel(
     bool okb[PF];
     // Loads are unconditional (a step past the end re-reads the last one, a frame outside [0, L) reads frame 0 of the row) and the
     // zeroing happens when the value is used: a select right after the load would make the wave wait for it at once.
-    auto load = [&](int slot, int s) {                         // s: step index of this wave, (tap, g) = divmod(s0 + s, g8)
-        const int sg = s0 + (s < ns ? s : ns - 1), tap = sg / g8, g = sg - tap * g8;
+    // Steps are requested in order, each once: a running (step, tap, channel group) instead of a division per step.  Requests
+    // past the wave's last step repeat it and are marked unreal.
+    int cu_sg = s0, cu_tap = s0 / g8, cu_g = s0 - cu_tap * g8, cu_left = ns;
+    auto next_step = [&](int& sg, int& tap, int& g, bool& real) {
+        sg = cu_sg; tap = cu_tap; g = cu_g; real = cu_left > 0;
+        if (cu_left > 1) {
+            ++cu_sg;
+            if (++cu_g == g8) { cu_g = 0; ++cu_tap; }
+        }
+        --cu_left;
+    };
+    auto load = [&](int slot) {
+        int sg, tap, g;
+        bool real;
+        next_step(sg, tap, g, real);
         if constexpr (SPLIT) {
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) {
@@ -399,7 +420,7 @@ __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void lin_kernel(
         }
         const int col = n + tap - a.pad;
         const bool ok = col >= 0 && col < a.L;
-        okb[slot] = ok && s < ns;
+        okb[slot] = ok && real;
         const unsigned off = ok ? xlane + (unsigned)((tap - a.pad) * 4) : (unsigned)((SPLIT ? 8 : 1) * half * a.x_ld) * 4u;
 #pragma unroll
         for (int j = 0; j < NB; ++j) B[slot][j] = buf_load(xr_, off, (unsigned)(g * (SPLIT ? 16 : 4) + j) * xrow2);
@@ -408,33 +429,100 @@ __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void lin_kernel(
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
     float ln_s1 = 0.f, ln_s2 = 0.f;                            // LN_IN: this lane's share of its frame's sum and sum of squares
+    f32x2 ln_p1 = {0.f, 0.f}, ln_p2 = {0.f, 0.f};              // the split form keeps them in pairs (packed adds and fmas)
+    // one step of the split form on a lane's eight x values and the two blocks' planes
+    auto split_step = [&](const float* bx, bool ok, const u32x4* s0p, const u32x4* s1p) {
+        u32x4 P[3];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            // a layer with a folded LayerNorm has one tap and no padding: its loads are never out of range, and what a lane
+            // past the last frame reads only reaches outputs that are not stored
+            const float b0 = LN_IN || ok ? bx[2 * q] : 0.f, b1 = LN_IN || ok ? bx[2 * q + 1] : 0.f;
+            if constexpr (LN_IN) {
+                const f32x2 bb = {b0, b1};
+                ln_p1 += bb;
+                ln_p2 = __builtin_elementwise_fma(bb, bb, ln_p2);
+            }
+            unsigned p0, p1, p2;
+            split_pair(b0, b1, p0, p1, p2);
+            P[0][q] = p0; P[1][q] = p1; P[2][q] = p2;
+        }
+        constexpr int ta[6] = {0, 2, 1, 0, 1, 0}, tb[6] = {2, 0, 1, 1, 0, 0};   // small partial products first
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, s0p[ta[k]]),
+                                                           __builtin_bit_cast(bf16x8_t, P[tb[k]]), acc0, 0, 0, 0);
+            if constexpr (MB == 2)
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, s1p[ta[k]]),
+                                                               __builtin_bit_cast(bf16x8_t, P[tb[k]]), acc1, 0, 0, 0);
+        }
+    };
+    if constexpr (WLDS) {
+        // Stage st = steps 2 st and 2 st + 1.  Its 12 KiB are 768 pieces of 16 bytes, block 0's two steps (384 pieces, contiguous
+        // in memory) then block 1's; thread tid moves pieces tid, 256 + tid and 512 + tid.  One barrier per stage: a buffer is
+        // rewritten two stages later, after the barrier of the stage between, which no wave passes before all have read it.
+        const int nst = ns / 2;
+        unsigned goff[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int pc = c * 256 + tid;
+            goff[c] = (pc >= 384 ? w1d + (unsigned)(pc - 384) * 16u : (unsigned)pc * 16u);
+        }
+        u32x4 G[3];
+        auto gload = [&](int st) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) G[c] = buf_load4u(wr_, goff[c], w0s + (unsigned)st * (2u * WSTEP));
+        };
+        float BX[2][8];                                        // x of a stage's two steps, requested a stage ahead
+        bool okx[2];
+        auto xload = [&](int slot) {                           // as load() above, the x half only
+            int sg, tap, g;
+            bool real;
+            next_step(sg, tap, g, real);
+            const int col = n + tap - a.pad;
+            const bool ok = col >= 0 && col < a.L;
+            okx[slot] = ok && real;
+            const unsigned off = ok ? xlane + (unsigned)((tap - a.pad) * 4) : (unsigned)(8 * half * a.x_ld) * 4u;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) BX[slot][j] = buf_load(xr_, off, (unsigned)(g * 16 + j) * xrow2);
+        };
+        gload(0);
+        xload(0);
+        xload(1);
+        __builtin_amdgcn_sched_barrier(0);
+        for (int st = 0; st < nst; ++st) {
+            u32x4* const wb = wls + (st & 1) * 768;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) wb[c * 256 + tid] = G[c];
+            __builtin_amdgcn_sched_barrier(0);
+            gload(st + 1 < nst ? st + 1 : st);                 // in flight under this stage's products
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                u32x4 W0[3], W1[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    W0[pl] = wb[t * 192 + pl * 64 + lane];
+                    W1[pl] = wb[384 + t * 192 + pl * 64 + lane];
+                }
+                split_step(BX[t], okx[t], W0, W1);
+                __builtin_amdgcn_sched_barrier(0);
+                xload(t);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    } else {
 #pragma unroll
     for (int i = 0; i < PF; ++i) {
-        load(i, i);
+        load(i);
         __builtin_amdgcn_sched_barrier(0);                     // in slot order: the loop's first wait then leaves PF - 1 groups in flight
     }
     for (int s = 0; s < ns; s += PF) {
 #pragma unroll
         for (int i = 0; i < PF; ++i) {
             if constexpr (SPLIT) {
-                u32x4 P[3];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float b0 = okb[i] ? B[i][2 * q] : 0.f, b1 = okb[i] ? B[i][2 * q + 1] : 0.f;
-                    if constexpr (LN_IN) { ln_s1 += b0 + b1; ln_s2 = fmaf(b0, b0, fmaf(b1, b1, ln_s2)); }
-                    unsigned p0, p1, p2;
-                    split_pair(b0, b1, p0, p1, p2);
-                    P[0][q] = p0; P[1][q] = p1; P[2][q] = p2;
-                }
-                constexpr int ta[6] = {0, 2, 1, 0, 1, 0}, tb[6] = {2, 0, 1, 1, 0, 0};   // small partial products first
-#pragma unroll
-                for (int k = 0; k < 6; ++k) {
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, S0[i][ta[k]]),
-                                                                   __builtin_bit_cast(bf16x8_t, P[tb[k]]), acc0, 0, 0, 0);
-                    if constexpr (MB == 2)
-                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, S1[i][ta[k]]),
-                                                                       __builtin_bit_cast(bf16x8_t, P[tb[k]]), acc1, 0, 0, 0);
-                }
+                split_step(B[i], okb[i], S0[i], S1[i]);
             } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -445,9 +533,10 @@ __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void lin_kernel(
             }
             }
             __builtin_amdgcn_sched_barrier(0);                 // keep the refill of this slot here, PF steps ahead of its use
-            load(i, s + i + PF);
+            load(i);
             __builtin_amdgcn_sched_barrier(0);
         }
+    }
     }
     float ln_mean = 0.f, ln_rstd = 0.f;                        // LN_IN: set once the frame's sums are complete
     // accumulator r of a lane: channel 8 (r / 4) + 4 (lane / 32) + r % 4 of its block of 32, frame lane % 32 of the tile.
@@ -502,6 +591,7 @@ __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void lin_kernel(
             if (co0 + e < a.Cout) a.y[z * a.y_bs + (size_t)(co0 + e) * a.y_ld + n] = has_res ? v[e] + pres[LN_IN ? 0 : gi][e] : v[e];
     };
 
+    if constexpr (LN_IN && SPLIT) { ln_s1 = ln_p1[0] + ln_p1[1]; ln_s2 = ln_p2[0] + ln_p2[1]; }
     if constexpr (LN_IN) {                                     // the two halves of a wave hold the two channel parities of a frame
         ln_s1 += __shfl_xor(ln_s1, 32);
         ln_s2 += __shfl_xor(ln_s2, 32);
@@ -786,7 +876,12 @@ int launch_lin(const LinArgs& a, int out_act, int rows, hipStream_t st) {
     } while (0)
     static const int deep_below = getenv("S3CFM_DEEP_BELOW") ? atoi(getenv("S3CFM_DEEP_BELOW")) : 1200;
     const bool deep = (long long)L * rows < deep_below;        // columns of the launch
-    if (split) { if (deep) S3_LIN_FORMS(S3_LIN_LAUNCH_SPLIT, true); else S3_LIN_FORMS(S3_LIN_LAUNCH_SPLIT, false); }
+    static const bool wlds = !(getenv("S3CFM_WLDS") && atoi(getenv("S3CFM_WLDS")) == 0);
+    if (split && ks == 1 && blocks == 2 && wlds) {             // the large launches of the split form: weights once per workgroup, through LDS
+        if (a.rsum && out_act == OUT_GELU) hipLaunchKernelGGL((lin_kernel<1, 2, OUT_GELU, true, true, false, true>), grid, block, 0, st, LIN_LEAD(a), a);
+        else if (a.rsum) hipLaunchKernelGGL((lin_kernel<1, 2, OUT_NONE, true, true, false, true>), grid, block, 0, st, LIN_LEAD(a), a);
+        else hipLaunchKernelGGL((lin_kernel<1, 2, OUT_NONE, false, true, false, true>), grid, block, 0, st, LIN_LEAD(a), a);
+    } else if (split) { if (deep) S3_LIN_FORMS(S3_LIN_LAUNCH_SPLIT, true); else S3_LIN_FORMS(S3_LIN_LAUNCH_SPLIT, false); }
     else { if (deep) S3_LIN_FORMS(S3_LIN_LAUNCH, true); else S3_LIN_FORMS(S3_LIN_LAUNCH, false); }
 #undef S3_LIN_FORMS
 #undef S3_LIN_LAUNCH

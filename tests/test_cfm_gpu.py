@@ -162,11 +162,13 @@ def test_token_to_waveform_chain_with_the_packaged_decoder(sd, split):
 
 @pytest.mark.parametrize("split", [False, True], ids=["fp32", "split_bf16"])
 @pytest.mark.parametrize("Cin,Cout,K,pad,L", [(256, 256, 1, 0, 1000), (320, 256, 3, 2, 77), (1024, 256, 1, 0, 333), (512, 256, 3, 2, 50),
-                                               (256, 1024, 1, 0, 1), (256, 80, 1, 0, 97), (256, 1024, 1, 0, 4200), (256, 1024, 1, 0, 1000), (256, 1536, 1, 0, 1000), (1024, 256, 1, 0, 1100)])
+                                               (256, 1024, 1, 0, 1), (256, 80, 1, 0, 97), (256, 1024, 1, 0, 4200), (256, 1024, 1, 0, 1000), (256, 1536, 1, 0, 1000), (1024, 256, 1, 0, 1100),
+                                               (256, 512, 1, 0, 8200), (320, 512, 3, 2, 8199)])
 def test_linear_kernel_against_fp64(Cin, Cout, K, pad, L, split):
     """Every shape class the estimator launches: the four workgroup forms (8-, 4- and 2-way split of the reduction, none:
     chosen by the number of tiles; 1100 frames x 256 channels takes one 32-channel block per wave), causal taps, ragged
-    lengths, 80 output channels, GELU and the residual add."""
+    lengths, 80 output channels, GELU and the residual add.  The launches of 8200 frames take the form without a split of the
+    reduction, whose split-bf16 variant shares a workgroup's weight planes through LDS."""
     from chatterbox_vllm_amd.cfm_decoder import linear_op
     g = torch.Generator().manual_seed(Cin + Cout + K + L)
     x = torch.randn(2, Cin, L, generator=g)
@@ -187,7 +189,7 @@ def test_linear_kernel_against_fp64(Cin, Cout, K, pad, L, split):
 
 
 @pytest.mark.parametrize("split", [False, True], ids=["fp32", "split_bf16"])
-@pytest.mark.parametrize("Cout,L,offset", [(1536, 1000, 0.0), (1024, 333, 3.0), (1024, 4200, -1.0), (256, 40, 0.5)])
+@pytest.mark.parametrize("Cout,L,offset", [(1536, 1000, 0.0), (1024, 333, 3.0), (1024, 4200, -1.0), (256, 40, 0.5), (1536, 2750, 0.7)])
 def test_linear_kernel_with_the_layer_norm_folded_in(Cout, L, offset, split):
     """norm1 / norm3 of a transformer block ride in the layer that consumes them (LinArgs::rsum): W LayerNorm(x) + b against
     fp64, with channel means away from zero (the folded form subtracts mean * row-sum after the product), for every

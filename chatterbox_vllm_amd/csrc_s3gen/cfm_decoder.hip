@@ -38,6 +38,21 @@ __device__ __forceinline__ float mish(float x) {
     return x * (t / (t + 2.0f));
 }
 
+// GELU, x Phi(x), with Phi(-|x|) = erfc(|x| / sqrt 2) / 2 from the rational approximation 7.1.26 of Abramowitz & Stegun
+// (absolute error of erfc below 1.5e-7, so of the result below 0.75e-7 |x|; no cancellation on the negative side): a dozen
+// instructions without a branch where the library erff takes both of its branches in most waves (a quarter of the
+// feed-forward layer's epilogue)
+__device__ __forceinline__ float gelu(float x) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float tail = 0.5f * (p * t) * __builtin_amdgcn_exp2f(-1.44269504088896340736f * z * z);    // Phi(-|x|)
+    return x * (x < 0.f ? tail : 1.0f - tail);
+}
+
 enum { LN_PLAIN = 0, LN_MISH = 1, LN_MISH_ADD = 2 };
 // LayerNorm over the 256 channels of every frame of a [row][256][T] tensor (eps 1e-5): 8 frames x 32 channel groups per
 // workgroup, mean, then the centred sum of squares.  LN_MISH applies Mish to the result, LN_MISH_ADD then adds add[c]
@@ -322,8 +337,15 @@ __global__ __launch_bounds__(256) void attn_kernel(
 // In the split form a step's operands are 8 KiB per wave for twelve 32-cycle matrix instructions, and sixteen waves per
 // CU then ask the vector memory path for more bytes per cycle (64 B) than it returns; shared, the weights are 1.5 KiB
 // per wave and step there and 6 KiB from LDS (128 B per cycle).
+#ifndef S3_LIN_OCC_WIDE
+#define S3_LIN_OCC_WIDE 1
+#endif
+#ifndef S3_LIN_OCC_WIDE_SPLIT
+#define S3_LIN_OCC_WIDE_SPLIT 1
+#endif
+#define S3_LIN_OCC(KSPLIT, DEEP, SPLIT) ((KSPLIT) == 1 && !(DEEP) ? ((SPLIT) ? S3_LIN_OCC_WIDE_SPLIT : S3_LIN_OCC_WIDE) : 1)
 template <int KSPLIT, int MB, int OUT_ACT, bool LN_IN, bool SPLIT = false, bool DEEP = true, bool WLDS = false>
-__global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void lin_kernel(
+__global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256, S3_LIN_OCC(KSPLIT, DEEP, SPLIT)) void lin_kernel(
         // Leading plain arguments reach the waves in SGPRs set up at wave launch (the library is built with kernel-argument
         // preloading, which takes no struct): the fields of LinArgs that the first addresses are made of, passed a second time.
         const float* lead_x, const float* lead_wt, size_t lead_x_bs, int lead_x_ld, int lead_Cin, int lead_CoutPad, int lead_K,
@@ -331,6 +353,14 @@ __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void lin_kernel(
     LinArgs a = a_;
     a.x = lead_x; a.wt = lead_wt; a.x_bs = lead_x_bs; a.x_ld = lead_x_ld; a.Cin = lead_Cin; a.CoutPad = lead_CoutPad; a.K = lead_K;
     a.L = lead_L; a.pad = lead_pad; a.Cout = lead_Cout;
+#ifdef S3_LIN_TIMELINE
+    long long tl[8];
+    tl[0] = (long long)__builtin_readcyclecounter();
+    tl[6] = (long long)wall_clock64();
+#define S3_LIN_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); tl[i] = (long long)__builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define S3_LIN_STAMP(i) do { } while (0)
+#endif
     constexpr int PF = SPLIT ? (DEEP ? 2 : 1) : (DEEP ? 4 : 2);     // steps of operands in flight (a split step holds twice the channels)
     constexpr int RW = 16 * MB;                                // accumulator rows per lane: MB blocks of 32 channels per wave
     static_assert(MB == 2 || (MB == 1 && KSPLIT <= 4), "one block per wave needs at least four rows per wave to finish");
@@ -457,6 +487,7 @@ __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void lin_kernel(
                                                                __builtin_bit_cast(bf16x8_t, P[tb[k]]), acc1, 0, 0, 0);
         }
     };
+    S3_LIN_STAMP(1);
     if constexpr (WLDS) {
         // Stage st = steps 2 st and 2 st + 1.  Its 12 KiB are 768 pieces of 16 bytes, block 0's two steps (384 pieces, contiguous
         // in memory) then block 1's; thread tid moves pieces tid, 256 + tid and 512 + tid.  One barrier per stage: a buffer is
@@ -538,6 +569,7 @@ __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void lin_kernel(
         }
     }
     }
+    S3_LIN_STAMP(2);
     float ln_mean = 0.f, ln_rstd = 0.f;                        // LN_IN: set once the frame's sums are complete
     // accumulator r of a lane: channel 8 (r / 4) + 4 (lane / 32) + r % 4 of its block of 32, frame lane % 32 of the tile.
     // Rows are finished four at a time (r % 4 = 0 .. 3: four consecutive channels): one 16-byte store per lane into the
@@ -550,7 +582,7 @@ __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void lin_kernel(
         for (int e = 0; e < 4; ++e) {
             if constexpr (LN_IN) v[e] = ln_rstd * (acc4[e] - ln_mean * prsum[gi][e]) + pbias[gi][e];
             else v[e] = acc4[e] + pbias[gi][e];
-            if constexpr (OUT_ACT == OUT_GELU) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752f));
+            if constexpr (OUT_ACT == OUT_GELU) v[e] = gelu(v[e]);
             else if constexpr (OUT_ACT == OUT_SWISH) v[e] = v[e] * (1.0f / (1.0f + expf(-v[e])));
             else if constexpr (OUT_ACT == OUT_LRELU) v[e] = v[e] > 0.f ? v[e] : v[e] * 0.01f;
         }
@@ -606,6 +638,7 @@ __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void lin_kernel(
             if (lane < 32) { lnst[(w * 2) * 32 + lane] = ln_s1; lnst[(w * 2 + 1) * 32 + lane] = ln_s2; }
         }
         __syncthreads();
+        S3_LIN_STAMP(3);
         if constexpr (LN_IN) {                                 // the parts of the reduction in wave order, like the accumulators
             ln_s1 = lnst[(ntile * KSPLIT * 2) * 32 + (lane & 31)];
             ln_s2 = lnst[(ntile * KSPLIT * 2 + 1) * 32 + (lane & 31)];
@@ -638,12 +671,17 @@ __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void lin_kernel(
             ln_mean = ln_s1 * inv_c;
             ln_rstd = 1.0f / sqrtf(fmaxf(ln_s2 * inv_c - ln_mean * ln_mean, 0.f) + a.ln_eps);
         }
-        // the operands of group gi + 1 are requested before group gi is finished: two groups of values live at a time
+        // the operands of group gi + EPI_AHEAD are requested before group gi is finished: EPI_AHEAD + 1 groups of values live at a time
+#ifndef S3_LIN_EPI_AHEAD
+#define S3_LIN_EPI_AHEAD 1
+#endif
+        constexpr int EPI_AHEAD = S3_LIN_EPI_AHEAD;
         __builtin_amdgcn_sched_barrier(0);
-        load_epilogue_operands(0);
+#pragma unroll
+        for (int gi = 0; gi < EPI_AHEAD && gi < NG; ++gi) load_epilogue_operands(gi);
 #pragma unroll
         for (int gi = 0; gi < NG; ++gi) {
-            if (gi + 1 < NG) load_epilogue_operands(gi + 1);
+            if (gi + EPI_AHEAD < NG) load_epilogue_operands(gi + EPI_AHEAD);
             __builtin_amdgcn_sched_barrier(0);
             float v[4];
 #pragma unroll
@@ -652,6 +690,16 @@ __global__ __launch_bounds__(KSPLIT == 8 ? 512 : 256) void lin_kernel(
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+#ifdef S3_LIN_TIMELINE
+    S3_LIN_STAMP(4);
+    tl[7] = (long long)wall_clock64();
+    if (a_.timeline && lane == 0) {
+        long long* dst = a_.timeline + ((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (blockDim.x / 64) + w) * 8;
+        if constexpr (KSPLIT == 1) tl[3] = tl[2];
+        tl[5] = 0;
+        for (int i = 0; i < 8; ++i) dst[i] = tl[i];
+    }
+#endif
 }
 
 // Weights in lin_kernel's fp32 tile order -> three bf16 planes in the operand order of v_mfma_f32_32x32x16_bf16:
@@ -1289,6 +1337,40 @@ static int op_linear(const float* x_dev, int32_t Cin, int32_t L, int32_t ld, con
     }
     const int rc = time_launches(iters, st, avg_us, [&]() { return launch_lin(a, gelu ? OUT_GELU : OUT_NONE, kRows, st); });
     S3_HIP_CHECK(hipStreamSynchronize(st));
+#ifdef S3_LIN_TIMELINE
+    if (rc == 0 && iters > 0) {
+        // one more launch with stamps: per wave start, loop start, loop end, merge done, end (shader clock) and start / end in
+        // the 100 MHz wall clock; printed as means over the waves and the spread of the starts and ends
+        const size_t cap = (size_t)1 << 20;                    // waves
+        long long* tl = nullptr;
+        S3_HIP_CHECK(hipMalloc(&tl, cap * 8 * sizeof(long long)));
+        S3_HIP_CHECK(hipMemset(tl, 0, cap * 8 * sizeof(long long)));
+        a.timeline = tl;
+        if (launch_lin(a, gelu ? OUT_GELU : OUT_NONE, kRows, st)) return 1;
+        S3_HIP_CHECK(hipStreamSynchronize(st));
+        std::vector<long long> h(cap * 8);
+        S3_HIP_CHECK(hipMemcpy(h.data(), tl, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+        hipFree(tl);
+        double sum[4] = {0, 0, 0, 0};
+        long long w0 = -1, w1 = 0, n = 0;
+        std::vector<long long> starts, ends;
+        for (size_t i = 0; i < cap; ++i) {
+            const long long* t = &h[i * 8];
+            if (!t[0]) continue;
+            ++n;
+            sum[0] += (double)(t[1] - t[0]); sum[1] += (double)(t[2] - t[1]); sum[2] += (double)(t[3] - t[2]); sum[3] += (double)(t[4] - t[3]);
+            if (w0 < 0 || t[6] < w0) w0 = t[6];
+            if (t[7] > w1) w1 = t[7];
+            starts.push_back(t[6]); ends.push_back(t[7]);
+        }
+        std::sort(starts.begin(), starts.end()); std::sort(ends.begin(), ends.end());
+        auto pct = [&](const std::vector<long long>& v, double q) { return (double)(v[(size_t)(q * (v.size() - 1))] - w0) / 100.0; };
+        fprintf(stderr, "  timeline: %lld waves; shader cycles per wave: prologue %.0f, loop %.0f, merge wait %.0f, epilogue %.0f; launch %.1f us; "
+                        "wave starts at 10/50/90/100 %%: %.1f %.1f %.1f %.1f us; ends at 10/50/90 %%: %.1f %.1f %.1f us\n",
+                n, sum[0] / n, sum[1] / n, sum[2] / n, sum[3] / n, (double)(w1 - w0) / 100.0, pct(starts, 0.1), pct(starts, 0.5), pct(starts, 0.9),
+                pct(starts, 1.0), pct(ends, 0.1), pct(ends, 0.5), pct(ends, 0.9));
+    }
+#endif
     return rc;
 }
 

@@ -93,6 +93,9 @@ struct LinArgs {
     // split_weights_kernel), and the products taken on split operands (cfm_split.h); needs K * Cin / 16 steps to divide by the
     // launch's reduction split, which launch_lin checks (it falls back to wt otherwise)
     const unsigned short* wsp;
+#ifdef S3_LIN_TIMELINE
+    long long* timeline;                     // tools/cfm_lin_probe.py on a build with -DS3_LIN_TIMELINE: eight stamps per wave
+#endif
 };
 enum { OUT_NONE = 0, OUT_GELU = 1, OUT_SWISH = 2, OUT_LRELU = 3 };   // OUT_LRELU: slope 0.01
 int launch_lin(const LinArgs& a, int out_act, int rows, hipStream_t st);

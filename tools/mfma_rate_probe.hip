@@ -69,7 +69,49 @@ __global__ __launch_bounds__(256) void probe(const u32x4* __restrict__ in, float
     if (lane == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
+// The fp32 matrix instruction (v_mfma_f32_32x32x2_f32, 64 cycles) in the same bare loop: four accumulators in turn, 64 per
+// iteration, long enough (milliseconds) for the clock to settle under the load.
+__global__ __launch_bounds__(256) void probe_f32(const float* __restrict__ in, float* __restrict__ out, int iters) {
+    const int lane = threadIdx.x;
+    float a[16], b[16];
+    for (int i = 0; i < 16; ++i) { a[i] = in[(i * 256 + lane) % 16384]; b[i] = in[((i + 16) * 256 + lane) % 16384]; }
+    f32x16 c0, c1, c2, c3;
+    for (int i = 0; i < 16; ++i) { c0[i] = 0.f; c1[i] = 0.f; c2[i] = 0.f; c3[i] = 0.f; }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], b[(k * 5) % 16], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[(k + 1) % 16], b[(k * 5) % 16], c1, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], b[(k * 7) % 16], c2, 0, 0, 0);
+            c3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[(k + 1) % 16], b[(k * 7) % 16], c3, 0, 0, 0);
+        }
+    }
+    float s = 0.f;
+    for (int i = 0; i < 16; ++i) s += c0[i] + c1[i] + c2[i] + c3[i];
+    out[blockIdx.x * 256 + lane] = s;
+}
+
 int main() {
+    {
+        const int grid = 256, iters = 4000;
+        std::vector<float> hf(16384);
+        float* fin; float* fout;
+        hipMalloc(&fin, hf.size() * 4); hipMalloc(&fout, grid * 256 * 4);
+        for (int data = 0; data < 2; ++data) {
+            for (auto& v : hf) v = data ? (float)(rand() % 2001 - 1000) * 1e-3f : 0.f;
+            hipMemcpy(fin, hf.data(), hf.size() * 4, hipMemcpyHostToDevice);
+            hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+            for (int rep = 0; rep < 4; ++rep) {
+                hipEventRecord(e0);
+                hipLaunchKernelGGL(probe_f32, dim3(grid), dim3(256), 0, 0, fin, fout, iters);
+                hipEventRecord(e1); hipEventSynchronize(e1);
+                float ms; hipEventElapsedTime(&ms, e0, e1);
+                printf("fp32 32x32x2 data %s rep %d: kernel %.2f ms, %.1f TFLOP/s (64 cycles each at %.2f GHz)\n", data ? "random" : "zeros ", rep, ms,
+                       (double)grid * 4 * iters * 64 * 4096.0 / (ms * 1e-3) / 1e12, (double)iters * 64 * 64 / (ms * 1e-3) / 1e9);
+            }
+        }
+        hipFree(fin); hipFree(fout);
+    }
     const int iters = 200, grid = 256;
     std::vector<unsigned> h(4096 * 4);
     u32x4* in; float* out; long long* cyc;

@@ -158,7 +158,8 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned vo
 // softmax statistics are per lane (one exchange between the two halves of the wave), the probabilities sit in the accumulator
 // layout that the second product wants as its B operand, and O^T[d][query] += V[d][key] P^T[key][query] takes V frame-major
 // ([frame][512], written that way by the q/k/v projection) so that its A operand is 32 consecutive floats per key.
-// K and V tiles come straight from global memory (L2 hits after the first pass, see the workgroup order); Q lives in registers.
+// K and V tiles come straight from global memory (L2 hits after the first pass, see the workgroup order); Q lives in LDS, shared
+// by the workgroup's waves (or in registers, the earlier form kept for comparison).
 struct AttnArgs {
     const float* q; const float* k; size_t qk_bs; int ld;     // [row][512][ld] channel-major, head h at channels 64 h ..
     const float* vt; size_t vt_bs;                            // [row][L][kVtLd] frame-major
@@ -171,8 +172,12 @@ struct AttnArgs {
 // QT: 32-query tiles per wave (1 to 3).  With more tiles every K and V value a wave loads feeds more matrix work and the
 // wave has more independent accumulators in flight (QT = 2 runs a tile 25 % faster than QT = 1); the launcher picks the QT
 // whose workgroup count packs best into the CUs (launch_attn).
-template <int QT>
-__global__ __launch_bounds__(256) void attn_kernel(
+// QLDS: the workgroup's queries (shared by its four waves) in LDS instead of 32 registers per tile in every wave: 132 / 190 / 249
+// registers for 1 / 2 / 3 tiles instead of 210 / 312 / 457, i.e. three / two / two workgroups per CU instead of two / one / one,
+// so that one wave's softmax runs under another's matrix instructions (2 000 frames 166 -> 150 us, 4 000 frames 616 -> 534 =
+// 123 TFLOP/s; 1 000 frames 46.9 -> 42.9 with one tile per wave).
+template <int QT, bool QLDS = false>
+__global__ __launch_bounds__(256, QLDS ? 2 : 1) void attn_kernel(
         // leading plain arguments travel in preloaded SGPRs (see lin_kernel)
         const float* lead_q, const float* lead_k, const float* lead_vt, size_t lead_qk_bs, size_t lead_vt_bs, int lead_ld, int lead_L,
         int lead_rows, AttnArgs a_) {
@@ -195,14 +200,27 @@ __global__ __launch_bounds__(256) void attn_kernel(
         }
         return;
     }
-    float Q[QT][32];
+    __shared__ float qs[QLDS ? QT * 64 * 32 : 1];              // [tile][dim][query]
+    float Q[QLDS ? 1 : QT][QLDS ? 1 : 32];
+    if constexpr (QLDS) {
+        for (int i = tid; i < QT * 64 * 32; i += 256) {
+            const int u = i >> 11, d = (i >> 5) & 63, qn = (qt * QT + u) * 32 + (i & 31);
+            qs[i] = a.q[b * a.qk_bs + (size_t)(h * 64 + d) * a.ld + (qn < a.L ? qn : a.L - 1)] * kQScale;
+        }
+        __syncthreads();
+    } else {
 #pragma unroll
-    for (int u = 0; u < QT; ++u) {
-        const int qn = (qt * QT + u) * 32 + col;
-        const float* qp = a.q + b * a.qk_bs + (size_t)(h * 64 + half) * a.ld + (qn < a.L ? qn : a.L - 1);
+        for (int u = 0; u < QT; ++u) {
+            const int qn = (qt * QT + u) * 32 + col;
+            const float* qp = a.q + b * a.qk_bs + (size_t)(h * 64 + half) * a.ld + (qn < a.L ? qn : a.L - 1);
 #pragma unroll
-        for (int kk = 0; kk < 32; ++kk) Q[u][kk] = qp[(size_t)(2 * kk) * a.ld] * kQScale;
+            for (int kk = 0; kk < 32; ++kk) Q[u][kk] = qp[(size_t)(2 * kk) * a.ld] * kQScale;
+        }
     }
+    auto qval = [&](int u, int kk) -> float {
+        if constexpr (QLDS) return qs[(u * 64 + 2 * kk + half) * 32 + col];
+        else return Q[u][kk];
+    };
     f32x16 o0[QT], o1[QT];
     float m[QT], l[QT];
 #pragma unroll
@@ -245,7 +263,7 @@ __global__ __launch_bounds__(256) void attn_kernel(
 #pragma unroll
         for (int kk = 0; kk < 32; ++kk)
 #pragma unroll
-            for (int u = 0; u < QT; ++u) s[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(kr[kk], Q[u][kk], s[u], 0, 0, 0);
+            for (int u = 0; u < QT; ++u) s[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(kr[kk], qval(u, kk), s[u], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         load_k(t + 4 < ntiles ? t + 4 : t);                    // the last tile loads itself again: no branch to schedule around
         __builtin_amdgcn_sched_barrier(0);
@@ -943,23 +961,35 @@ namespace {
 
 int launch_attn(const AttnArgs& a, hipStream_t st) {
     static const int force = getenv("S3CFM_ATTN_QT") ? atoi(getenv("S3CFM_ATTN_QT")) : 0;
-    // Query tiles per wave: a workgroup of QT tiles costs about QT units of time on its CU and a launch takes as long as
-    // its most loaded CU: pick the QT whose number of workgroups packs best into the 256 CUs (1 100 frames: 560 workgroups of
-    // one tile or 192 of three take 3 units, 288 of two take 4).
+    static const bool qlds = !(getenv("S3CFM_ATTN_QLDS") && atoi(getenv("S3CFM_ATTN_QLDS")) == 0);
+    // Query tiles per wave (QT).  A workgroup of QT tiles costs its CU about QT units of matrix work and a launch takes as long
+    // as its most loaded CU, k = ceil(workgroups / 256) of them: pick the QT with the smallest k x QT.  With the queries in LDS
+    // (the default) three / two / two workgroups of 1 / 2 / 3 tiles are resident on a CU at a time, so that one wave's softmax
+    // runs under another's matrix instructions; a workgroup that runs alone (k = 1, or the last one after full sets) lacks that
+    // and costs a tenth more, and a tile costs less the more tiles share a wave's K and V loads.  Fitted to per-launch times at
+    // 500 .. 3 000 frames with one and four utterances per call (1 000 frames: 512 workgroups of one tile 42.9 us, 256 of two
+    // 45.5; 2 000: two tiles 150, one 160, three 209; 3 000: three tiles 324, two 406).
     const int tiles = (a.L + 31) / 32;
     int best = 1;
     double best_cost = 1e30;
     for (int qt = 1; qt <= 3; ++qt) {                          // four tiles per wave would spill registers
-        const long long wgs = (long long)((tiles + qt - 1) / qt) * a.rows * kHeads;
-        const double per_tile = qt == 1 ? 1.02 : 1.0;           // measured: one tile per wave is a few per cent slower per tile
-        const double cost = (double)((wgs + 255) / 256) * qt * per_tile;
+        const long long wgs = (long long)((tiles + qt - 1) / qt) * a.rows * kHeads, k = (wgs + 255) / 256;
+        double cost;
+        if (qlds) {
+            const int occ = qt == 1 ? 3 : 2;
+            const double per_tile = qt == 1 ? 1.05 : (qt == 2 ? 1.0 : 0.95);
+            cost = (double)k * qt * per_tile * (k % occ == 1 ? 1.1 : 1.0);
+        } else {
+            cost = (double)k * qt * (qt == 1 ? 1.02 : 1.0);    // queries in registers: one workgroup of two or three tiles per CU
+        }
         if (cost < best_cost - 1e-9) { best_cost = cost; best = qt; }
     }
     if (force >= 1 && force <= 3) best = force;
     const dim3 grid((tiles + best - 1) / best * a.rows * kHeads);
-    if (best == 1) hipLaunchKernelGGL(attn_kernel<1>, grid, dim3(256), 0, st, a.q, a.k, a.vt, a.qk_bs, a.vt_bs, a.ld, a.L, a.rows, a);
-    else if (best == 2) hipLaunchKernelGGL(attn_kernel<2>, grid, dim3(256), 0, st, a.q, a.k, a.vt, a.qk_bs, a.vt_bs, a.ld, a.L, a.rows, a);
-    else hipLaunchKernelGGL(attn_kernel<3>, grid, dim3(256), 0, st, a.q, a.k, a.vt, a.qk_bs, a.vt_bs, a.ld, a.L, a.rows, a);
+#define S3_ATTN_LAUNCH(QT, QL) hipLaunchKernelGGL((attn_kernel<QT, QL>), grid, dim3(256), 0, st, a.q, a.k, a.vt, a.qk_bs, a.vt_bs, a.ld, a.L, a.rows, a)
+    if (qlds) { if (best == 1) S3_ATTN_LAUNCH(1, true); else if (best == 2) S3_ATTN_LAUNCH(2, true); else S3_ATTN_LAUNCH(3, true); }
+    else { if (best == 1) S3_ATTN_LAUNCH(1, false); else if (best == 2) S3_ATTN_LAUNCH(2, false); else S3_ATTN_LAUNCH(3, false); }
+#undef S3_ATTN_LAUNCH
     S3_HIP_CHECK(hipGetLastError());
     return 0;
 }

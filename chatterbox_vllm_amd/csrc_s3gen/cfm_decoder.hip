@@ -54,44 +54,47 @@ __device__ __forceinline__ float gelu(float x) {
 }
 
 enum { LN_PLAIN = 0, LN_MISH = 1, LN_MISH_ADD = 2 };
-// LayerNorm over the 256 channels of every frame of a [row][256][T] tensor (eps 1e-5): 8 frames x 32 channel groups per
-// workgroup, mean, then the centred sum of squares.  LN_MISH applies Mish to the result, LN_MISH_ADD then adds add[c]
-// (the time-embedding projection of a resnet block, matcha/decoder.py:58).  In place is allowed.
+// LayerNorm over the 256 channels of every frame of a [row][256][T] tensor (eps 1e-5): 16 frames x 16 channel groups per
+// workgroup (64-byte pieces of a channel row per load), mean, then the centred sum of squares.  LN_MISH applies Mish to the
+// result, LN_MISH_ADD then adds add[c] (the time-embedding projection of a resnet block, matcha/decoder.py:58).  In place is
+// allowed.
+constexpr int kLnFrames = 16;
 template <int MODE>
 __global__ __launch_bounds__(256) void ln256_kernel(const float* x, float* y, int ld, size_t bs, int T, const float* __restrict__ gamma,
                                                     const float* __restrict__ beta, const float* __restrict__ add) {
-    __shared__ float red[32][9];
-    const int tx = threadIdx.x & 7, cy = threadIdx.x >> 3;
-    const int t = blockIdx.x * 8 + tx;
+    constexpr int G = 256 / kLnFrames, PER = kC / G;            // channel groups, channels per thread
+    __shared__ float red[G][kLnFrames + 1];
+    const int tx = threadIdx.x % kLnFrames, cy = threadIdx.x / kLnFrames;
+    const int t = blockIdx.x * kLnFrames + tx;
     const bool ok = t < T;
     const float* xb = x + blockIdx.y * bs;
     float* yb = y + blockIdx.y * bs;
-    float v[8];
+    float v[PER];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = ok ? xb[(size_t)(cy + 32 * i) * ld + t] : 0.f;
+    for (int i = 0; i < PER; ++i) v[i] = ok ? xb[(size_t)(cy + G * i) * ld + t] : 0.f;
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) s += v[i];
+    for (int i = 0; i < PER; ++i) s += v[i];
     red[cy][tx] = s;
     __syncthreads();
     float mean = 0.f;
 #pragma unroll
-    for (int i = 0; i < 32; ++i) mean += red[i][tx];
+    for (int i = 0; i < G; ++i) mean += red[i][tx];
     mean *= 1.0f / kC;
     __syncthreads();
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { const float d = v[i] - mean; q = fmaf(d, d, q); }
+    for (int i = 0; i < PER; ++i) { const float d = v[i] - mean; q = fmaf(d, d, q); }
     red[cy][tx] = q;
     __syncthreads();
     float var = 0.f;
 #pragma unroll
-    for (int i = 0; i < 32; ++i) var += red[i][tx];
+    for (int i = 0; i < G; ++i) var += red[i][tx];
     const float rstd = 1.0f / sqrtf(var * (1.0f / kC) + 1e-5f);
     if (ok)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int c = cy + 32 * i;
+        for (int i = 0; i < PER; ++i) {
+            const int c = cy + G * i;
             float o = (v[i] - mean) * rstd * gamma[c] + beta[c];
             if constexpr (MODE != LN_PLAIN) o = mish(o);
             if constexpr (MODE == LN_MISH_ADD) o = o + add[c];
@@ -1011,7 +1014,7 @@ int run_lin(const s3cfm* h, const Lin& l, const float* x, int x_rows, float* y, 
 }
 
 int run_ln(const s3cfm* h, int mode, const float* x, float* y, int L, const Norm& n, const float* add, hipStream_t st) {
-    const dim3 grid((L + 7) / 8, h->rows);
+    const dim3 grid((L + kLnFrames - 1) / kLnFrames, h->rows);
     const size_t bs = (size_t)kC * h->ld;
     if (mode == LN_PLAIN) hipLaunchKernelGGL(ln256_kernel<LN_PLAIN>, grid, dim3(256), 0, st, x, y, h->ld, bs, L, n.g, n.b, add);
     else if (mode == LN_MISH) hipLaunchKernelGGL(ln256_kernel<LN_MISH>, grid, dim3(256), 0, st, x, y, h->ld, bs, L, n.g, n.b, add);

@@ -233,11 +233,11 @@ def test_qkv_projection_writes_v_frame_major(split):
 
 
 @pytest.mark.parametrize("split", [False, True])
-@pytest.mark.parametrize("L", [1, 31, 32, 100, 129, 1000, 1100, 2101])
+@pytest.mark.parametrize("L", [1, 31, 32, 100, 129, 1000, 1100, 2000, 2101])
 def test_attention_kernel_against_fp64(L, split):
     """softmax(q k^T / 8) v per head against fp64, lengths around the 32-key tile and the four-wave split, with score
-    spreads of tens of units so that the running maximum moves; 1000, 1100 and 2101 frames make the launcher pick two,
-    three and one query tiles per wave.  split: the form that holds every operand as three bf16 values and takes six partial
+    spreads of tens of units so that the running maximum moves; 1100, 2000 and 2101 frames make the fp32 launcher pick
+    three, two and one query tiles per wave (1000: one tile on the fp32 form, two on the split form).  split: the form that holds every operand as three bf16 values and takes six partial
     products per product on the bf16 matrix instruction, to the same tolerance."""
     from chatterbox_vllm_amd.cfm_decoder import attention_op
     g = torch.Generator().manual_seed(L)
